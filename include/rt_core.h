@@ -1,0 +1,137 @@
+/*
+ * rt_core.h — C ABI of librt_core.so, the MI355X (gfx950) path-tracing core.
+ *
+ * Drop-in boundary: the reference (bspafford/Raytracing) has no plugin/FFI interface; its seam to
+ * the integrator is the set of OpenGL calls in SSBO.cpp / computeShader.cpp / main.cpp.  Every entry
+ * point below replaces one of those calls one-for-one (reference file:line cited per function;
+ * paths are relative to /root/reference/Raytracing/).  INTEGRATION.md shows the edits a maintainer
+ * makes in SSBO.cpp, computeShader.cpp, Texture.cpp and main.cpp to bind them.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function returns rt_status
+ * (0 = RT_OK); rt_last_error() gives the message.  The callee copies every input before returning
+ * (the reference frees its host arrays right after SSBO::Bind, model.cpp:607-610).  A context is
+ * bound to one GPU and is not thread-safe (the reference drives GL from one thread).  There is no
+ * CPU fallback: without a HIP device rt_create fails with RT_ERR_NO_DEVICE.
+ */
+#ifndef RT_CORE_H
+#define RT_CORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t rt_status;
+enum {
+    RT_OK = 0,
+    RT_ERR_NO_DEVICE = 1,      /* no HIP device / hipSetDevice failed */
+    RT_ERR_INVALID = 2,        /* bad argument (NULL, slot/image out of range, size not a record multiple) */
+    RT_ERR_NOT_READY = 3,      /* render requested before slots 0..5 and the image size were provided */
+    RT_ERR_HIP = 4,            /* a HIP call or kernel failed; message has hipGetErrorString */
+    RT_ERR_SCENE = 5           /* inconsistent scene buffers (index out of range, cyclic BVH ...) */
+};
+
+typedef struct rt_ctx rt_ctx;
+
+typedef struct rt_config {
+    int32_t device;            /* HIP device ordinal */
+    int32_t rank, world_size;  /* informational (multi-GPU partition is driven by rt_render_region) */
+    int32_t reserved;
+} rt_config;
+
+/* Buffer slots = the SSBO binding points of shader.comp:78-83. */
+enum {
+    RT_SLOT_VERTICES = 0,      /* Vertex[]          80 B  VBO.h:9-17                         */
+    RT_SLOT_MESH_MATRICES = 1, /* mat4[]            64 B  column-major, model.cpp:562-563    */
+    RT_SLOT_MATERIALS = 2,     /* MaterialData[]    80 B  model.h:8-39                       */
+    RT_SLOT_BVH_NODES = 3,     /* GPUBoundingBox[]  48 B  model.h:130-142, DFS pre-order     */
+    RT_SLOT_TRIANGLES = 4,     /* Triangle[]       128 B  model.h:41-70, original order      */
+    RT_SLOT_LIGHTS = 5         /* GPULight[]        48 B  light.h:14-23                      */
+};
+
+/* Output images = image units 0..3 of shader.comp:9-12 (RGBA32F, row 0 = bottom). */
+enum { RT_IMAGE_COLOR = 0, RT_IMAGE_ALBEDO = 1, RT_IMAGE_NORMAL = 2, RT_IMAGE_DEPTH = 3 };
+
+/* Replaces ComputeShader::ComputeShader(const char*) (computeShader.cpp:7-23): creates the
+ * integrator "program" on one GPU.  cfg may be NULL (device 0). */
+rt_status rt_create(rt_ctx** out, const rt_config* cfg);
+/* Replaces ComputeShader::Delete (computeShader.cpp:29-31).  Frees all device memory. */
+void rt_destroy(rt_ctx* ctx);
+/* Message of the last failing call on ctx (ctx may be NULL for rt_create failures). */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Replaces SSBO::Bind(const void* data, GLuint size, GLuint slot) (SSBO.cpp:5-17): copies `bytes`
+ * bytes now; re-binding a slot replaces its content.  The reference record layouts above are the
+ * input format; the compacted device layout is derived lazily at the next render. */
+rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_t bytes);
+
+/* Replace ComputeShader::setInt/setFloat/setVec2/setVec3/setVec4/setMat4 (computeShader.cpp:53-75):
+ * by-name, sticky.  Live names (shader.comp:85-102): numLights, hasSun, camPos, camForward, camRight,
+ * camUp, aspect, fov, samplesPerPixel, maxBounces, offset.  Unknown names (projection, invProj, view,
+ * invView, time ...) are accepted and ignored, as glGetUniformLocation == -1 is in GL.
+ * Extension names (no reference counterpart): traversalMode (0 = culled/ordered, 1 = reference-order
+ * exhaustive), samplesPerPass. */
+rt_status rt_set_int(rt_ctx* ctx, const char* name, int32_t v);
+rt_status rt_set_float(rt_ctx* ctx, const char* name, float v);
+rt_status rt_set_vec2(rt_ctx* ctx, const char* name, const float v[2]);
+rt_status rt_set_vec3(rt_ctx* ctx, const char* name, const float v[3]);
+rt_status rt_set_vec4(rt_ctx* ctx, const char* name, const float v[4]);
+rt_status rt_set_mat4(rt_ctx* ctx, const char* name, const float m[16]);
+
+/* Replaces Texture::Texture(GLuint slot, glm::vec2 size) x4 (Texture.cpp:36-47, main.cpp:85-88) and the
+ * resize path main.cpp:293-306: (re)allocates the four W x H RGBA32F output images, zero-filled. */
+rt_status rt_resize(rt_ctx* ctx, uint32_t width, uint32_t height);
+
+/* Replaces Texture::Texture(image, type, slot) + glGetTextureHandleARB/glMakeTextureHandleResidentARB
+ * (Texture.cpp:5-34, model.cpp:546-559): uploads a decoded RGBA8 image (row 0 first, as stbi returns it)
+ * and returns the 64-bit handle to store in MaterialData.  Sampling = LINEAR, REPEAT, level 0. */
+rt_status rt_create_texture(rt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint64_t* handle_out);
+
+/* Replaces the 64x64-tile glDispatchCompute loop + glMemoryBarrier (main.cpp:126-141): traces the whole
+ * frame (all samplesPerPixel, all bounces) into the four images and returns when they are complete. */
+rt_status rt_render_frame(rt_ctx* ctx);
+/* Partition form used by the multi-GPU driver (no reference counterpart; the reference is single-GPU):
+ * traces pixels [x,x+w) x [y,y+h) and samples [spp_begin, spp_end) of samplesPerPixel.  Pixels outside the
+ * region are zero in the color image; AOV images are written only when spp_begin == 0. */
+rt_status rt_render_region(rt_ctx* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
+                           uint32_t spp_begin, uint32_t spp_end);
+
+/* Replaces glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, dst) (main.cpp:157,163,169; Renderer.cpp:100):
+ * blocking copy of W*H*4 floats, row 0 = bottom. */
+rt_status rt_read_image(rt_ctx* ctx, uint32_t image, float* dst_rgba);
+/* Replaces glTexSubImage2D write-back after denoise (main.cpp:184). */
+rt_status rt_write_image(rt_ctx* ctx, uint32_t image, const float* src_rgba);
+/* Device address of an image (W*H*4 floats) for zero-copy consumers on the same GPU (RCCL reduce,
+ * device-side denoisers).  No reference counterpart. */
+rt_status rt_image_device_ptr(rt_ctx* ctx, uint32_t image, void** dev_ptr);
+
+/* Counters of the last rt_render_* call (no reference counterpart; feeds the Mrays/s metric). */
+typedef struct rt_stats {
+    uint64_t rays_primary;     /* lineCast calls at bounce 0                                   */
+    uint64_t rays_bounce;      /* lineCast calls at bounce > 0                                 */
+    uint64_t rays_shadow;      /* shadow lineCast calls actually traced                        */
+    uint64_t rays_shadow_skipped; /* shadow casts the reference issues whose result cannot matter (N.L <= 0) */
+    uint64_t node_visits;      /* BVH node records fetched (only when statsLevel >= 2)         */
+    uint64_t tri_tests;        /* ray-triangle tests executed (only when statsLevel >= 2)      */
+    double   ms_total;         /* wall time of the render call, host clock                     */
+    double   ms_extend;        /* summed HIP-event time of the closest-hit kernels             */
+    double   ms_shade;         /* ... of the shading kernels                                   */
+    double   ms_shadow;        /* ... of the shadow (any-hit) kernels                          */
+    uint64_t launches_extend;  /* kernel launches behind ms_extend                             */
+    uint64_t launches_shadow;
+} rt_stats;
+rt_status rt_get_stats(rt_ctx* ctx, rt_stats* out);
+
+/* Debug / parity taps (no reference counterpart): primary-hit triangle ids (reference numbering, -1 = miss)
+ * and hit locations of sample 0, W*H int32 / W*H*3 floats, valid after a render whose sample range contains 0. */
+rt_status rt_read_primary_hits(rt_ctx* ctx, int32_t* tri_ids, float* hit_locs);
+/* Closest-hit query on caller rays with the same kernel the integrator uses (parity tests):
+ * origins/dirs n*3 floats (host) -> tri_ids n int32 (reference numbering), hit_locs n*3 floats. */
+rt_status rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint64_t n,
+                        int32_t* tri_ids, float* hit_locs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_CORE_H */

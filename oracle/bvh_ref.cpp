@@ -1,0 +1,198 @@
+// ORACLE — test infrastructure only.  Never linked, imported or called by the product path
+// (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/).
+//
+// CPU restatement of the reference's SAH BVH build, function by function:
+//   Model::computeForAxis   /root/reference/Raytracing/model.cpp:417-462
+//   Model::buildBVH         model.cpp:467-513
+//   Model::convertToGPU     model.cpp:515-530
+//   BoundingBox ctors / calcSurfaceArea   model.h:81-118
+//   GPUBoundingBox ctor     model.h:137-141
+// Input  = the 128-byte Triangle records in original (flatten) order (model.h:41-70).
+// Output = the 48-byte GPUBoundingBox records in DFS pre-order (what SSBO::Bind uploads to slot 3).
+// Contract: libstdc++ std::sort on the same input order; g++ -O2 -ffp-contract=off.
+//
+// Pinning: the reference has no tests or fixtures.  SURVEY.md §8c records FNV-1a-64 hashes of the
+// node bytes produced by the reference's own builder (model.cpp:416-530 compiled verbatim in the
+// survey container); tests/test_oracle_bvh.py checks this restatement against those five hashes.
+#include <algorithm>
+#include <cfloat>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace {
+
+struct V3 { float x, y, z; float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); } };
+inline V3 vmin(V3 a, V3 b) { return {b.x < a.x ? b.x : a.x, b.y < a.y ? b.y : a.y, b.z < a.z ? b.z : a.z}; }  // glm::min: (y < x) ? y : x
+inline V3 vmax(V3 a, V3 b) { return {a.x < b.x ? b.x : a.x, a.y < b.y ? b.y : a.y, a.z < b.z ? b.z : a.z}; }  // glm::max: (x < y) ? y : x
+
+// model.h:41-70 (128 B).  Only the fields the builder reads are named.
+struct Triangle {
+    uint32_t indices[3]; uint32_t _p0;
+    V3 p1; float _p1; V3 p2; float _p2; V3 p3; float _p3;
+    V3 centroidLoc; float _p4;
+    V3 minBounds; float _p5;
+    V3 maxBounds; uint32_t meshIndex;
+    uint32_t materialIndex; uint32_t pad1[2]; uint32_t _tail;
+};
+static_assert(sizeof(Triangle) == 128, "Triangle must be 128 bytes");
+
+struct GPUBoundingBox {   // model.h:130-142 (48 B)
+    V3 minLoc; float pad1; V3 maxLoc; uint32_t isLeaf; int32_t children[4];
+};
+static_assert(sizeof(GPUBoundingBox) == 48, "GPUBoundingBox must be 48 bytes");
+
+inline float surfaceArea(V3 mn, V3 mx) {   // model.h:115-118
+    V3 e{mx.x - mn.x, mx.y - mn.y, mx.z - mn.z};
+    return 2.f * (e.x * e.y + e.y * e.z + e.z * e.x);
+}
+
+struct BoundingBox {     // model.h:72-108
+    BoundingBox* left = nullptr;
+    BoundingBox* right = nullptr;
+    std::vector<const Triangle*> triangles;
+    V3 minLoc, maxLoc;
+    BoundingBox(BoundingBox* l, BoundingBox* r) : left(l), right(r) {
+        V3 lmin = l ? l->minLoc : V3{FLT_MAX, FLT_MAX, FLT_MAX};
+        V3 lmax = l ? l->maxLoc : V3{-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        V3 rmin = r ? r->minLoc : V3{FLT_MAX, FLT_MAX, FLT_MAX};
+        V3 rmax = r ? r->maxLoc : V3{-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        minLoc = vmin(lmin, rmin);
+        maxLoc = vmax(lmax, rmax);
+    }
+    explicit BoundingBox(std::vector<const Triangle*> t) : triangles(std::move(t)) {
+        minLoc = V3{FLT_MAX, FLT_MAX, FLT_MAX};
+        maxLoc = V3{-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (const Triangle* tr : triangles) {
+            const V3 pts[3] = {tr->p1, tr->p2, tr->p3};
+            for (const V3& p : pts) { minLoc = vmin(minLoc, p); maxLoc = vmax(maxLoc, p); }
+        }
+    }
+};
+
+using It = std::vector<const Triangle*>::iterator;
+
+// model.cpp:417-462
+std::pair<float, int> computeForAxis(It begin, It end, std::vector<const Triangle*>& tris, int axis) {
+    tris = std::vector<const Triangle*>(begin, end);
+    std::sort(tris.begin(), tris.end(), [axis](const Triangle* a, const Triangle* b) {
+        return a->centroidLoc[axis] < b->centroidLoc[axis];
+    });
+    size_t size = tris.size();
+    std::vector<V3> prefixMin(size), prefixMax(size), suffixMin(size), suffixMax(size);
+    prefixMin[0] = tris[0]->minBounds;
+    prefixMax[0] = tris[0]->maxBounds;
+    for (size_t i = 1; i < size; ++i) {
+        prefixMin[i] = vmin(prefixMin[i - 1], tris[i]->minBounds);
+        prefixMax[i] = vmax(prefixMax[i - 1], tris[i]->maxBounds);
+    }
+    suffixMin[size - 1] = tris[size - 1]->minBounds;
+    suffixMax[size - 1] = tris[size - 1]->maxBounds;
+    for (int i = (int)size - 2; i >= 0; i--) {
+        suffixMin[i] = vmin(suffixMin[i + 1], tris[i]->minBounds);
+        suffixMax[i] = vmax(suffixMax[i + 1], tris[i]->maxBounds);
+    }
+    float bestCost = FLT_MAX;
+    int bestIndex = (int)(size / 2);
+    for (int i = 0; i < (int)size; i++) {
+        float parentSA = surfaceArea(vmin(prefixMin[i], suffixMin[i]), vmax(prefixMax[i], suffixMax[i]));
+        // `* i` converts int -> float; `* (size - i)` converts size_t -> float (model.cpp:452-453)
+        float cost = 1.f + ((surfaceArea(prefixMin[i], prefixMax[i]) / parentSA) * (float)i +
+                            (surfaceArea(suffixMin[i], suffixMax[i]) / parentSA) * (float)(size - (size_t)i));
+        if (cost < bestCost) { bestCost = cost; bestIndex = i; }
+    }
+    return {bestCost, bestIndex};
+}
+
+struct DepthExceeded {};
+
+// model.cpp:467-513.  `depth` is only a guard against the reference's unbounded recursion on
+// degenerate input (split index 0); the reference itself would overflow its stack there.
+BoundingBox* buildBVH(It begin, It end, int depth) {
+    size_t size = (size_t)(end - begin);
+    if (size <= 4) return new BoundingBox(std::vector<const Triangle*>(begin, end));
+    if (depth > 512) throw DepthExceeded{};
+    std::vector<const Triangle*> axisData[3];
+    std::pair<float, int> r0, r1, r2;
+    if (size > 2048) {   // thread use does not affect the result; small nodes run inline
+        auto f0 = std::async(std::launch::async, computeForAxis, begin, end, std::ref(axisData[0]), 0);
+        auto f1 = std::async(std::launch::async, computeForAxis, begin, end, std::ref(axisData[1]), 1);
+        r2 = computeForAxis(begin, end, axisData[2], 2);
+        r0 = f0.get(); r1 = f1.get();
+    } else {
+        r0 = computeForAxis(begin, end, axisData[0], 0);
+        r1 = computeForAxis(begin, end, axisData[1], 1);
+        r2 = computeForAxis(begin, end, axisData[2], 2);
+    }
+    float best = r0.first; int bestAxis = 0; int bestIndex = r0.second;
+    if (r1.first < best) { best = r1.first; bestAxis = 1; bestIndex = r1.second; }
+    if (r2.first < best) { best = r2.first; bestAxis = 2; bestIndex = r2.second; }
+    auto& sorted = axisData[bestAxis];
+    BoundingBox* left; BoundingBox* right;
+    if (size > 10000) {
+        auto lf = std::async(std::launch::async, [&]() { return buildBVH(sorted.begin(), sorted.begin() + bestIndex, depth + 1); });
+        right = buildBVH(sorted.begin() + bestIndex, sorted.end(), depth + 1);
+        left = lf.get();
+    } else {
+        left = buildBVH(sorted.begin(), sorted.begin() + bestIndex, depth + 1);
+        right = buildBVH(sorted.begin() + bestIndex, sorted.end(), depth + 1);
+    }
+    return new BoundingBox(left, right);
+}
+
+// model.cpp:515-530 + GPUBoundingBox ctor model.h:137-141
+uint32_t convertToGPU(BoundingBox* box, std::vector<GPUBoundingBox>& out, const Triangle* base) {
+    uint32_t cur = (uint32_t)out.size();
+    GPUBoundingBox g;
+    std::memset(&g, 0, sizeof g);   // pad1 is uninitialised in the reference (Q17): zero here
+    const V3 pinf{FLT_MAX, FLT_MAX, FLT_MAX}, ninf{-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    g.minLoc = vmin(box->left ? box->left->minLoc : pinf, box->right ? box->right->minLoc : pinf);
+    g.maxLoc = vmax(box->left ? box->left->maxLoc : ninf, box->right ? box->right->maxLoc : ninf);
+    g.isLeaf = (!box->left && !box->right) ? 1u : 0u;
+    g.children[0] = g.children[1] = g.children[2] = g.children[3] = -1;
+    out.push_back(g);
+    if (out[cur].isLeaf) {
+        for (size_t k = 0; k < 4; k++)
+            out[cur].children[k] = (box->triangles.size() > k && box->triangles[k]) ? (int32_t)(box->triangles[k] - base) : -1;
+    } else {
+        int32_t l = box->left ? (int32_t)convertToGPU(box->left, out, base) : -1;
+        out[cur].children[0] = l;
+        int32_t r = box->right ? (int32_t)convertToGPU(box->right, out, base) : -1;
+        out[cur].children[1] = r;
+    }
+    return cur;
+}
+
+void deleteTree(BoundingBox* b) { if (!b) return; deleteTree(b->left); deleteTree(b->right); delete b; }
+
+}  // namespace
+
+extern "C" {
+
+// Returns 0 on success; *nodes_out is malloc'ed (free with bvh_ref_free).  -2 = degenerate input
+// (the reference would recurse without bound).
+int bvh_ref_build(const void* triangles, uint32_t n_tris, void** nodes_out, uint32_t* n_nodes_out) {
+    const Triangle* base = (const Triangle*)triangles;
+    std::vector<const Triangle*> ptrs(n_tris);
+    for (uint32_t i = 0; i < n_tris; i++) ptrs[i] = base + i;
+    BoundingBox* root;
+    try { root = buildBVH(ptrs.begin(), ptrs.end(), 0); } catch (DepthExceeded&) { return -2; }
+    std::vector<GPUBoundingBox> out;
+    out.reserve((size_t)n_tris);
+    convertToGPU(root, out, base);
+    deleteTree(root);
+    void* mem = std::malloc(out.size() * sizeof(GPUBoundingBox) + 16);
+    if (!mem) return -1;
+    std::memcpy(mem, out.data(), out.size() * sizeof(GPUBoundingBox));
+    *nodes_out = mem;
+    *n_nodes_out = (uint32_t)out.size();
+    return 0;
+}
+
+void bvh_ref_free(void* p) { std::free(p); }
+
+}  // extern "C"

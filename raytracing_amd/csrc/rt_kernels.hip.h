@@ -1,0 +1,651 @@
+// gfx950 wavefront path-tracing kernels (included by rt_core.hip).
+//
+// Pipeline per sample r (one path per pixel in flight; DESIGN.md "Wavefront pipeline"):
+//   k_raygen            shader.comp:309-324   ray generation, queue 0
+//   for bounce b:
+//     k_extend          shader.comp:243-290   closest hit (lineCast) over queue b
+//     k_shade           shader.comp:329-452,524-531  miss/ambient, surface fetch, dielectric/GGX bounce,
+//                                              light evaluation -> pending contribution, queue b+1
+//     k_shadow          shader.comp:453-522   shadow lineCast per pending light, accumulate
+//   k_finalize          shader.comp:533-536   image stores
+// Compaction between stages: wave64 ballot + mbcnt prefix, one atomic per wave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "rt_types.h"
+#include "rt_math.h"
+
+namespace rt {
+
+#define RT_BLOCK 256
+
+struct PathBuffers {
+    float4* rayO;        // o.xyz, w = flag bits (bit0 refracting)
+    float4* rayD;        // d.xyz
+    float4* rayS;        // strength.xyz
+    float4* hit;         // hitLoc.xyz, w = reference triangle index bits (-1 miss)
+    float4* pend;        // [numLights][nslots] rgb of a light's contribution, w = 1 when a shadow ray is due
+    float4* accum;       // [nslots] running pixel colour (the shader's `color`)
+    uint32_t* queues;    // [2][nslots]
+    uint32_t* shadowQueue;
+    uint32_t* counters;  // [0..maxB] path-queue sizes per bounce, [maxB+1 .. 2maxB+1] shadow-queue sizes
+    uint32_t nslots;
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave64 append: returns this lane's output index (valid lanes only); one atomic per wave.
+__device__ __forceinline__ uint32_t wave_append(bool valid, uint32_t* counter) {
+    unsigned long long mask = __ballot(valid);
+    uint32_t n = (uint32_t)__popcll(mask);
+    uint32_t lanePrefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    uint32_t base = 0;
+    if (n) {
+        int leader = __ffsll((long long)mask) - 1;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, n);
+        base = (uint32_t)__shfl((int)base, leader, 64);
+    }
+    return base + lanePrefix;
+}
+
+__device__ __forceinline__ void slot_to_pixel(const FrameParams& F, uint32_t slot, int* px, int* py) {
+    uint32_t tile = slot >> 6, l = slot & 63u;
+    uint32_t tx = tile % (uint32_t)F.tilesX, ty = tile / (uint32_t)F.tilesX;
+    *px = F.rx + (int)(tx * 8u + (l & 7u));
+    *py = F.ry + (int)(ty * 8u + (l >> 3));
+}
+
+// ---------------------------------------------------------------------------------------------
+// shader.comp:171-184 — same float sequence; also returns tEnter for ordering / culling.
+__device__ __forceinline__ bool slab(v3 o, v3 inv, const float* lo, const float* hi, float* tEnterOut) {
+    float t0x = (lo[0] - o.x) * inv.x, t0y = (lo[1] - o.y) * inv.y, t0z = (lo[2] - o.z) * inv.z;
+    float t1x = (hi[0] - o.x) * inv.x, t1y = (hi[1] - o.y) * inv.y, t1z = (hi[2] - o.z) * inv.z;
+    float tminx = gmin(t0x, t1x), tminy = gmin(t0y, t1y), tminz = gmin(t0z, t1z);
+    float tmaxx = gmax(t0x, t1x), tmaxy = gmax(t0y, t1y), tmaxz = gmax(t0z, t1z);
+    float tEnter = gmax(gmax(tminx, tminy), tminz);
+    float tExit = gmin(gmin(tmaxx, tmaxy), tmaxz);
+    *tEnterOut = tEnter;
+    return tExit >= tEnter && tExit >= 0.0f;
+}
+
+struct HitRec { float dist; float t; int idx; int ref; v3 loc; };
+
+// shader.comp:104-125 + 269-276 on a pre-transformed triangle.
+template <bool EXACT>
+__device__ __forceinline__ void test_tri(const CTri* __restrict__ tris, int idx, v3 o, v3 d, HitRec& best) {
+    const float4* p = reinterpret_cast<const float4*>(tris + idx);
+    float4 A = p[0], B = p[1], C = p[2];
+    v3 v0 = mk(A.x, A.y, A.z), e1 = mk(A.w, B.x, B.y), e2 = mk(B.z, B.w, C.x);
+    v3 pv = cross3(d, e2);
+    float det = dot3(e1, pv);
+    if (fabsf(det) < 1e-8f) return;
+    float invDet = 1.0f / det;
+    v3 s = o - v0;
+    float u = dot3(s, pv) * invDet;
+    if (u < 0.0f || u > 1.0f) return;
+    v3 q = cross3(s, e1);
+    float v = dot3(d, q) * invDet;
+    if (v < 0.0f || u + v > 1.0f) return;
+    float t = dot3(e2, q) * invDet;
+    if (t < 1e-8f) return;
+    v3 h = o + d * t;
+    v3 oh = o - h;
+    float newDist = dot3(oh, oh);
+    // Reference: strict < in visit order.  Visit rank == array index, so (dist, idx) lexicographic
+    // minimum is the same winner under any traversal order.
+    bool better = EXACT ? (newDist < best.dist) : (newDist < best.dist || (newDist == best.dist && idx < best.idx));
+    if (better) {
+        best.dist = newDist; best.t = t; best.idx = idx; best.loc = h;
+        best.ref = __float_as_int(C.y);
+    }
+}
+
+struct StackRef {
+    uint2* lds;          // this lane's column in LDS: entry k at lds[k * RT_BLOCK]
+    uint2 spill[RT_SPILL_STACK];
+};
+
+// Closest hit == lineCast (shader.comp:243-290).
+//   EXACT:  reference order (right child first), no culling, leaf children always entered.
+//   !EXACT: near child first, distance culling with slack, padded leaf boxes.  Same winner: DESIGN.md.
+//   ANYHIT: stop at the first accepted hit with t-independent predicate `accept` (sun: any hit;
+//           point light: distance(hit, shadeLoc) < distToLight), see k_shadow.
+template <bool EXACT, bool COUNT>
+__device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, uint2* ldsCol, HitRec& best,
+                                            uint32_t& nNodes, uint32_t& nTris) {
+    best.dist = 3.40282347e+38f; best.t = __int_as_float(0x7f800000); best.idx = -1; best.ref = -1;
+    best.loc = mk(0.f, 0.f, 0.f);
+    v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float te;
+    if (COUNT) nNodes++;
+    if (!slab(o, inv, S.rootLo, S.rootHi, &te)) return false;
+    uint2 spill[RT_SPILL_STACK];
+    int sp = 0;
+    int cur = S.rootChild;
+    while (true) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT) nNodes++;
+            float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
+            float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
+            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            float t0, t1;
+            bool p0 = slab(o, inv, lo0, hi0, &t0);
+            bool p1 = slab(o, inv, lo1, hi1, &t1);
+            if (EXACT) {
+                // a leaf child's own box is never tested by the reference (Q2): enter unconditionally
+                p0 = p0 || (c0 < 0);
+                p1 = p1 || (c1 < 0);
+                // reference pops children.y first (shader.comp:281-284)
+                if (p0 && p1) {
+                    uint2 e; e.x = (uint32_t)c0; e.y = 0u;
+                    if (sp < RT_LDS_STACK) ldsCol[sp * RT_BLOCK] = e; else if (sp < RT_LDS_STACK + RT_SPILL_STACK) spill[sp - RT_LDS_STACK] = e;
+                    if (sp < RT_LDS_STACK + RT_SPILL_STACK) sp++;
+                    cur = c1; continue;
+                }
+                if (p1) { cur = c1; continue; }
+                if (p0) { cur = c0; continue; }
+            } else {
+                float lim = best.t + best.t * 1e-4f + S.cullAbs;
+                p0 = p0 && !(t0 > lim);
+                p1 = p1 && !(t1 > lim);
+                if (p0 && p1) {
+                    bool swap = t1 < t0;
+                    int nearC = swap ? c1 : c0, farC = swap ? c0 : c1;
+                    float farT = swap ? t0 : t1;
+                    uint2 e; e.x = (uint32_t)farC; e.y = __float_as_uint(farT);
+                    if (sp < RT_LDS_STACK) ldsCol[sp * RT_BLOCK] = e; else if (sp < RT_LDS_STACK + RT_SPILL_STACK) spill[sp - RT_LDS_STACK] = e;
+                    if (sp < RT_LDS_STACK + RT_SPILL_STACK) sp++;
+                    cur = nearC; continue;
+                }
+                if (p0) { cur = c0; continue; }
+                if (p1) { cur = c1; continue; }
+            }
+        } else {
+            int code = -cur - 1;
+            int first = code >> 3, cnt = code & 7;
+            for (int k = 0; k < cnt; k++) {
+                if (COUNT) nTris++;
+                test_tri<EXACT>(S.tris, first + k, o, d, best);
+            }
+        }
+        // pop
+        bool got = false;
+        while (sp > 0) {
+            sp--;
+            uint2 e = (sp < RT_LDS_STACK) ? ldsCol[sp * RT_BLOCK] : spill[sp - RT_LDS_STACK];
+            if (!EXACT) {
+                float lim = best.t + best.t * 1e-4f + S.cullAbs;
+                if (__uint_as_float(e.y) > lim) continue;
+            }
+            cur = (int)e.x; got = true; break;
+        }
+        if (!got) break;
+    }
+    return best.idx >= 0;
+}
+
+// Any-hit for shadow rays.  kind 1 (sun): occluded on any hit (shader.comp:481-483).
+// kind 0 (point): occluded when the closest hit H has distance(H, shadeLoc) < distToLight
+// (shader.comp:467-471).  In traversalMode 0 the first hit satisfying that predicate ends the walk and
+// boxes entered beyond distToLight (+slack) are skipped; traversalMode 1 runs the full closest-hit.
+template <bool COUNT>
+__device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, int kind, v3 shadeLoc, float distToLight,
+                                              uint2* ldsCol, uint32_t& nNodes, uint32_t& nTris) {
+    v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float te;
+    if (COUNT) nNodes++;
+    if (!slab(o, inv, S.rootLo, S.rootHi, &te)) return false;
+    // For point lights |d| = 1 so t ~ distance from o; o is within ~1e-5*|n| of shadeLoc.
+    float lim = (kind == 0) ? (distToLight + distToLight * 1e-3f + S.cullAbs * 4.0f) : __int_as_float(0x7f800000);
+    uint2 spill[RT_SPILL_STACK];
+    int sp = 0;
+    int cur = S.rootChild;
+    while (true) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT) nNodes++;
+            float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
+            float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
+            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            float t0, t1;
+            bool p0 = slab(o, inv, lo0, hi0, &t0) && !(t0 > lim);
+            bool p1 = slab(o, inv, lo1, hi1, &t1) && !(t1 > lim);
+            if (p0 && p1) {
+                uint2 e; e.x = (uint32_t)c1; e.y = 0u;
+                if (sp < RT_LDS_STACK) ldsCol[sp * RT_BLOCK] = e; else if (sp < RT_LDS_STACK + RT_SPILL_STACK) spill[sp - RT_LDS_STACK] = e;
+                if (sp < RT_LDS_STACK + RT_SPILL_STACK) sp++;
+                cur = c0; continue;
+            }
+            if (p0) { cur = c0; continue; }
+            if (p1) { cur = c1; continue; }
+        } else {
+            int code = -cur - 1;
+            int first = code >> 3, cnt = code & 7;
+            for (int k = 0; k < cnt; k++) {
+                if (COUNT) nTris++;
+                HitRec h; h.dist = 3.40282347e+38f; h.idx = -1; h.t = 0.f; h.ref = -1; h.loc = mk(0.f, 0.f, 0.f);
+                test_tri<true>(S.tris, first + k, o, d, h);
+                if (h.idx >= 0) {
+                    if (kind == 1) return true;
+                    v3 dl = h.loc - shadeLoc;
+                    if (sqrtf(dot3(dl, dl)) < distToLight) return true;
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        uint2 e = (sp < RT_LDS_STACK) ? ldsCol[sp * RT_BLOCK] : spill[sp - RT_LDS_STACK];
+        cur = (int)e.x;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shader.comp:309-324 for sample r, one thread per slot of the region's 8x8-tiled slot space.
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(FrameParams F, PathBuffers P, int r, uint32_t* queueOut, uint32_t* countOut) {
+    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+    bool valid = false;
+    if (slot < P.nslots) {
+        int px, py;
+        slot_to_pixel(F, slot, &px, &py);
+        valid = px < F.rx + F.rw && py < F.ry + F.rh;
+        if (valid) {
+            int N = F.gridN;
+            int gx = r % N, gy = r / N;
+            float jx = ((float)gx + 0.5f) / (float)N, jy = ((float)gy + 0.5f) / (float)N;
+            float ux = ((float)px + jx) / (float)F.width * 2.0f - 1.0f;
+            float uy = ((float)py + jy) / (float)F.height * 2.0f - 1.0f;
+            ux *= F.aspect;
+            float fx = ux * F.tanHalfFov;
+            float fy = uy * F.tanHalfFov;
+            v3 fwd = ld3(F.camForward), right = ld3(F.camRight), up = ld3(F.camUp);
+            v3 dir = (fwd + fx * right + fy * up);
+            P.rayO[slot] = make_float4(F.camPos[0], F.camPos[1], F.camPos[2], __uint_as_float(0u));
+            P.rayD[slot] = make_float4(dir.x, dir.y, dir.z, 0.f);
+            P.rayS[slot] = make_float4(F.initialStrength, F.initialStrength, F.initialStrength, 0.f);
+        }
+    }
+    uint32_t idx = wave_append(valid, countOut);
+    if (valid) queueOut[idx] = slot;
+}
+
+template <bool EXACT, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, PathBuffers P, const uint32_t* __restrict__ queue,
+                                                     const uint32_t* __restrict__ count, int isPrimary, DeviceStats* stats) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    uint32_t n = *count;
+    uint32_t nNodes = 0, nTris = 0;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        uint32_t slot = queue[i];
+        float4 o4 = P.rayO[slot], d4 = P.rayD[slot];
+        HitRec best;
+        closest_hit<EXACT, COUNT>(S, mk(o4.x, o4.y, o4.z), mk(d4.x, d4.y, d4.z), lds + threadIdx.x, best, nNodes, nTris);
+        P.hit[slot] = make_float4(best.loc.x, best.loc.y, best.loc.z, __int_as_float(best.ref));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(isPrimary ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)n);
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { nNodes += __shfl_down(nNodes, off, 64); nTris += __shfl_down(nTris, off, 64); }
+        if ((threadIdx.x & 63) == 0 && (nNodes | nTris)) {
+            atomicAdd(&stats->node_visits, (unsigned long long)nNodes);
+            atomicAdd(&stats->tri_tests, (unsigned long long)nTris);
+        }
+    }
+}
+
+// texture(sampler2D(handle), uv): LINEAR, REPEAT, level 0, RGBA8 unorm (Texture.cpp:5-34; GL 4.3 8.14).
+__device__ __forceinline__ float4 sample_tex(const SceneView& S, uint64_t handle, float u, float v) {
+    if (handle == 0 || handle > S.n_textures) return make_float4(0.f, 0.f, 0.f, 1.f);
+    TexDesc T = S.textures[handle - 1];
+    float fu = u * (float)T.width - 0.5f, fv = v * (float)T.height - 0.5f;
+    float iu = floorf(fu), iv = floorf(fv);
+    float a = fu - iu, b = fv - iv;
+    long long w = T.width, h = T.height;
+    long long i0 = (long long)iu % w; if (i0 < 0) i0 += w;
+    long long j0 = (long long)iv % h; if (j0 < 0) j0 += h;
+    long long i1 = (i0 + 1) % w, j1 = (j0 + 1) % h;
+    const uchar4* px = reinterpret_cast<const uchar4*>(T.rgba8);
+    uchar4 q00 = px[j0 * w + i0], q10 = px[j0 * w + i1], q01 = px[j1 * w + i0], q11 = px[j1 * w + i1];
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float4 o;
+    o.x = w00 * ((float)q00.x / 255.0f) + w10 * ((float)q10.x / 255.0f) + w01 * ((float)q01.x / 255.0f) + w11 * ((float)q11.x / 255.0f);
+    o.y = w00 * ((float)q00.y / 255.0f) + w10 * ((float)q10.y / 255.0f) + w01 * ((float)q01.y / 255.0f) + w11 * ((float)q11.y / 255.0f);
+    o.z = w00 * ((float)q00.z / 255.0f) + w10 * ((float)q10.z / 255.0f) + w01 * ((float)q01.z / 255.0f) + w11 * ((float)q11.z / 255.0f);
+    o.w = w00 * ((float)q00.w / 255.0f) + w10 * ((float)q10.w / 255.0f) + w01 * ((float)q01.w / 255.0f) + w11 * ((float)q11.w / 255.0f);
+    return o;
+}
+
+// shader.comp:193-241
+__device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float alpha) {
+    if (alpha == 0.f) return N;
+    rand1 = gclamp(rand1, 0.0001f, 0.9999f);
+    rand2 = gclamp(rand2, 0.0001f, 0.9999f);
+    alpha = gmax(alpha, 0.0001f);
+    float a2 = alpha * alpha;
+    float phi = (2.0f * 3.141592653589793f) * rand1;
+    float denom = 1.0f + (a2 - 1.0f) * rand2;
+    denom = gmax(denom, 0.000001f);
+    float cosTheta = sqrtf((1.0f - rand2) / denom);
+    cosTheta = gclamp(cosTheta, -1.0f, 1.0f);
+    float sinTheta = sqrtf(gmax(0.0f, 1.0f - cosTheta * cosTheta));
+    float sp, cp;
+    portable_sincos(phi, &sp, &cp);
+    v3 Ht = mk(sinTheta * cp, sinTheta * sp, cosTheta);
+    v3 T;
+    if (fabsf(N.z) < 0.999f) T = normalize3(cross3(mk(0.f, 0.f, 1.f), N));
+    else T = normalize3(cross3(mk(1.f, 0.f, 0.f), N));
+    v3 B = cross3(N, T);
+    v3 H = T * Ht.x + B * Ht.y + N * Ht.z;
+    float lenH = length3(H);
+    if (lenH < 1e-6f) return N;
+    return H / lenH;
+}
+
+// shader.comp:329-452 and 524-531 for one path; light loop body 486-521 is evaluated here and its
+// result parked in `pend` until k_shadow has traced the shadow ray (453-484).
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ queue,
+                                                    const uint32_t* __restrict__ count, uint32_t* queueOut, uint32_t* countOut,
+                                                    uint32_t* shadowCountOut, int r, int bounce,
+                                                    float4* imgAlbedo, float4* imgNormal, float4* imgDepth,
+                                                    int32_t* primTri, float* primHit, DeviceStats* stats) {
+    uint32_t n = *count;
+    uint32_t nIter = (n + RT_BLOCK * gridDim.x - 1) / (RT_BLOCK * gridDim.x);
+    uint32_t skipped = 0;
+    for (uint32_t it = 0; it < nIter; it++) {
+        uint32_t i = (it * gridDim.x + blockIdx.x) * RT_BLOCK + threadIdx.x;
+        bool live = i < n;
+        bool cont = false, wantShadow = false;
+        uint32_t slot = 0;
+        if (live) {
+            slot = queue[i];
+            float4 o4 = P.rayO[slot], d4 = P.rayD[slot], s4 = P.rayS[slot], h4 = P.hit[slot];
+            v3 rayLoc = mk(o4.x, o4.y, o4.z), rayDir = mk(d4.x, d4.y, d4.z), strength = mk(s4.x, s4.y, s4.z);
+            bool refracting = (__float_as_uint(o4.w) & 1u) != 0u;
+            int ref = __float_as_int(h4.w);
+            int px, py;
+            slot_to_pixel(F, slot, &px, &py);
+            v3 camPos = ld3(F.camPos);
+            if (ref < 0) {
+                // miss: shader.comp:331-336
+                v3 ambient = F.hasSun ? mk(0.4431372549f, 0.73725490196f, 1.f) : mk(0.f, 0.f, 0.f);
+                float4 c = P.accum[slot];
+                v3 cc = mk(c.x, c.y, c.z) + ambient * strength;
+                P.accum[slot] = make_float4(cc.x, cc.y, cc.z, 1.f);
+                if (r == 0 && bounce == 0 && primTri) primTri[(size_t)py * F.width + px] = -1;
+            } else {
+                v3 hitLoc = mk(h4.x, h4.y, h4.z);
+                const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
+                float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4], q5 = sp[5], q6 = sp[6];
+                v3 a = mk(q0.x, q0.y, q0.z), b = mk(q0.w, q1.x, q1.y), c = mk(q1.z, q1.w, q2.x);
+                v3 n1 = mk(q2.y, q2.z, q2.w), n2 = mk(q3.x, q3.y, q3.z), n3 = mk(q3.w, q4.x, q4.y);
+                float uv1x = q4.z, uv1y = q4.w, uv2x = q5.x, uv2y = q5.y, uv3x = q5.z, uv3y = q5.w;
+                uint32_t matIdx = __float_as_uint(q6.x);
+                // barycentric, shader.comp:132-151
+                v3 v0 = b - a, v1 = c - a, v2 = hitLoc - a;
+                float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
+                float denomB = d00 * d11 - d01 * d01;
+                float bv = (d11 * d20 - d01 * d21) / denomB;
+                float bw = (d00 * d21 - d01 * d20) / denomB;
+                float bu = 1.0f - bv - bw;
+                v3 hitNormal = (n1 * bu + n2 * bv + n3 * bw);
+                float hitU = uv1x * bu + uv2x * bv + uv3x * bw;
+                float hitV = uv1y * bu + uv2y * bv + uv3y * bw;
+                const RefMaterial* mp = S.materials + matIdx;
+                const float4* m4 = reinterpret_cast<const float4*>(mp);
+                float4 m0 = m4[0], m1 = m4[1], m2 = m4[2], m3 = m4[3], m4v = m4[4];
+                int hasBase = __float_as_int(m1.z), hasNormal = __float_as_int(m2.z), hasMR = __float_as_int(m3.z);
+                float transmission = m1.w, ior = m4v.x;
+                float metallicFactor, roughnessFactor;
+                if (hasMR == 1) {
+                    float4 t = sample_tex(S, mp->metallicRoughnessTexture, hitU, hitV);
+                    metallicFactor = t.x; roughnessFactor = t.y;
+                } else { metallicFactor = m2.w; roughnessFactor = m3.w; }
+                v3 normal;
+                if (hasNormal == 1) {
+                    uint32_t i1 = __float_as_uint(q6.y), i2 = __float_as_uint(q6.z), i3 = __float_as_uint(q6.w);
+                    const float* t1 = S.vertices[i1].tangent; const float* t2 = S.vertices[i2].tangent; const float* t3 = S.vertices[i3].tangent;
+                    v3 tangent = (ld3(t1) * bu + ld3(t2) * bv + ld3(t3) * bw);
+                    float handed = t1[3] * bu + t2[3] * bv + t3[3] * bw;
+                    float4 nt = sample_tex(S, mp->normalTexture, hitU, hitV);
+                    v3 normalTex = mk(nt.x, nt.y, nt.z) * 2.0f - mk(1.f, 1.f, 1.f);
+                    float normalStrength = 1.f;
+                    normalTex.x *= normalStrength; normalTex.y *= normalStrength;
+                    v3 bitangent = cross3(hitNormal, tangent) * handed;
+                    normal = tangent * normalTex.x + bitangent * normalTex.y + hitNormal * normalTex.z;
+                } else normal = hitNormal;
+
+                // reflect / refract, shader.comp:389-431
+                bool shouldReflect = true;
+                float rb = (float)(r * bounce);
+                if (transmission > 0) {
+                    float iorAir = 1.f;
+                    float cosi = gclamp(dot3(-rayDir, normal), -1.0f, 1.0f);
+                    float r0 = (iorAir - ior) / (iorAir + ior);
+                    r0 = r0 * r0;
+                    float reflectionStrength = r0 + (1.0f - r0) * pow5(1.0f - cosi);
+                    if (!refracting) {
+                        float rnd = hash13(mk((float)px * 2.3f, (float)py * 2.3f, rb * 18.f) * rayDir + rayLoc);
+                        if (rnd > reflectionStrength) {
+                            rayDir = refract3(rayDir, normal, iorAir / ior);
+                            rayLoc = hitLoc - normal * 1e-5f;
+                            strength = strength * transmission;
+                            refracting = true;
+                            shouldReflect = false;
+                        }
+                    } else {
+                        v3 newLoc = hitLoc + normal * 1e-5f;
+                        v3 newDir = refract3(rayDir, -normal, ior / iorAir);
+                        if (length3(newDir) == 0.f) {
+                            rayDir = reflect3(rayDir, -normal);
+                            rayLoc = hitLoc - normal * 1e-5f;
+                            refracting = true;
+                        } else {
+                            rayLoc = newLoc;
+                            rayDir = newDir;
+                            refracting = false;
+                        }
+                        shouldReflect = false;
+                    }
+                }
+                if (shouldReflect) {
+                    float h1 = hash13(mk((float)px, (float)py, rb) * rayDir + rayLoc);
+                    float h2 = hash13(mk((float)px * 37.f, (float)py * 37.f, rb * 37.f) * rayDir + rayLoc);
+                    v3 H = sample_ggx(normal, h1, h2, roughnessFactor);
+                    rayDir = reflect3(rayDir, H);
+                    rayLoc = hitLoc + (normal * 1e-5f);
+                }
+
+                // lighting set-up, shader.comp:433-451
+                v3 baseColor = mk(m0.x, m0.y, m0.z);
+                if (hasBase == 1) {
+                    float4 t = sample_tex(S, mp->baseColorTexture, hitU, hitV);
+                    baseColor = mk(t.x, t.y, t.z);
+                }
+                v3 viewDir = normalize3(camPos - hitLoc);
+                float dielectricF0 = .04f;
+                if (transmission > 0) { float e = (ior - 1.0f) / (ior + 1.0f); dielectricF0 = e * e; }
+                v3 F0 = mk(dielectricF0, dielectricF0, dielectricF0) * (1.0f - metallicFactor) + baseColor * metallicFactor;
+                float alpha = roughnessFactor * roughnessFactor;
+                const float PI = 3.14159265359f;
+                v3 diffuseColor = baseColor * (1.0f - metallicFactor);
+
+                if (r == 0 && bounce == 0) {
+                    size_t pix = (size_t)py * F.width + px;
+                    if (imgAlbedo) {
+                        imgAlbedo[pix] = make_float4(diffuseColor.x, diffuseColor.y, diffuseColor.z, 1.f);
+                        imgNormal[pix] = make_float4(normal.x / 2.f + 0.5f, normal.y / 2.f + 0.5f, normal.z / 2.f + 0.5f, 1.f);
+                        float dd = length3(camPos - hitLoc) / 255.f;
+                        imgDepth[pix] = make_float4(dd, dd, dd, 1.f);
+                    }
+                    if (primTri) {
+                        primTri[pix] = ref;
+                        primHit[pix * 3] = hitLoc.x; primHit[pix * 3 + 1] = hitLoc.y; primHit[pix * 3 + 2] = hitLoc.z;
+                    }
+                }
+
+                // light loop, shader.comp:453-522 minus the shadow lineCast (k_shadow)
+                for (int l = 0; l < F.numLights; l++) {
+                    const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
+                    float4 L0 = lp[0], L1 = lp[1], L2 = lp[2];
+                    uint32_t ltype = __float_as_uint(L1.w);
+                    v3 dirToLight = mk(0.f, 0.f, 0.f);
+                    float attenuation = 1.f;
+                    bool cast = false;
+                    if (ltype == 0u) {
+                        v3 toL = mk(L0.x, L0.y, L0.z) - hitLoc;
+                        dirToLight = normalize3(toL);
+                        float distToLight = length3(toL);
+                        attenuation = L0.w / (1.f + 1.f * distToLight + 1.f * distToLight * distToLight);
+                        cast = true;
+                    } else if (ltype == 1u) {
+                        dirToLight = -mk(L1.x, L1.y, L1.z);
+                        cast = true;
+                    }
+                    float NdotL = gmax(dot3(normal, dirToLight), 0.0f);
+                    float4 pendOut = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!(NdotL <= 0.0f)) {
+                        v3 Hh = normalize3(viewDir + dirToLight);
+                        float NdotH = gmax(dot3(normal, Hh), 0.0f);
+                        float NdotV = gmax(dot3(normal, viewDir), 0.0f);
+                        float cosTheta = gclamp(dot3(normal, -viewDir), 0.0f, 1.0f);
+                        v3 Fr = F0 + (1.0f - F0) * pow5(1.0f - cosTheta);
+                        float a2 = alpha * alpha;
+                        float denom = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
+                        float D = a2 / (PI * denom * denom);
+                        float k = (alpha + 1) * (alpha + 1) / 8.0f;
+                        float G_V = NdotV / (NdotV * (1.0f - k) + k);
+                        float G_L = NdotL / (NdotL * (1.0f - k) + k);
+                        float G = G_V * G_L;
+                        v3 specular = (D * Fr * G) / (4.0f * NdotV * NdotL + 0.001f);
+                        v3 diffuse = diffuseColor / PI;
+                        v3 radiance = mk(L2.x, L2.y, L2.z) * attenuation;
+                        v3 contrib = (diffuse + specular) * radiance * NdotL * strength;
+                        pendOut = make_float4(contrib.x, contrib.y, contrib.z, cast ? 1.f : 2.f);
+                        if (cast) wantShadow = true;
+                        else {
+                            // light type the shader does not know: no shadow test, contribution added directly
+                            float4 cA = P.accum[slot];
+                            P.accum[slot] = make_float4(cA.x + contrib.x, cA.y + contrib.y, cA.z + contrib.z, 1.f);
+                            pendOut.w = 0.f;
+                        }
+                    } else if (cast) skipped++;
+                    P.pend[(size_t)l * P.nslots + slot] = pendOut;
+                }
+
+                // shader.comp:524-530
+                if (transmission == 0.f)
+                    strength = strength * mk(gclamp(baseColor.x, 0.f, 1.f), gclamp(baseColor.y, 0.f, 1.f), gclamp(baseColor.z, 0.f, 1.f));
+                bool active = !(length3(strength) < F.strengthCutoff);
+                cont = active && (bounce + 1 < F.maxBounces);
+                if (cont || wantShadow) {
+                    P.rayO[slot] = make_float4(rayLoc.x, rayLoc.y, rayLoc.z, __uint_as_float(refracting ? 1u : 0u));
+                }
+                if (cont) {
+                    P.rayD[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.f);
+                    P.rayS[slot] = make_float4(strength.x, strength.y, strength.z, 0.f);
+                }
+            }
+        }
+        uint32_t qi = wave_append(cont, countOut);
+        if (cont) queueOut[qi] = slot;
+        uint32_t si = wave_append(wantShadow, shadowCountOut);
+        if (wantShadow) P.shadowQueue[si] = slot;
+    }
+    for (int off = 32; off > 0; off >>= 1) skipped += __shfl_down(skipped, off, 64);
+    if ((threadIdx.x & 63) == 0 && skipped) atomicAdd(&stats->rays_shadow_skipped, (unsigned long long)skipped);
+}
+
+// shader.comp:453-484 + the accumulate of 521, lights in order.
+template <bool EXACT, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
+                                                     DeviceStats* stats) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    uint32_t n = *count;
+    uint32_t nNodes = 0, nTris = 0, nRays = 0;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        uint32_t slot = P.shadowQueue[i];
+        float4 o4 = P.rayO[slot], h4 = P.hit[slot];
+        v3 o = mk(o4.x, o4.y, o4.z), hitLoc = mk(h4.x, h4.y, h4.z);
+        float4 acc = P.accum[slot];
+        bool dirty = false;
+        for (int l = 0; l < F.numLights; l++) {
+            float4 pe = P.pend[(size_t)l * P.nslots + slot];
+            if (pe.w != 1.f) continue;
+            const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
+            float4 L0 = lp[0], L1 = lp[1];
+            uint32_t ltype = __float_as_uint(L1.w);
+            v3 dirToLight; float distToLight = 0.f;
+            if (ltype == 0u) {
+                v3 toL = mk(L0.x, L0.y, L0.z) - hitLoc;
+                dirToLight = normalize3(toL);
+                distToLight = length3(toL);
+            } else dirToLight = -mk(L1.x, L1.y, L1.z);
+            nRays++;
+            bool occ;
+            if (EXACT) {
+                HitRec best;
+                bool h = closest_hit<true, COUNT>(S, o, dirToLight, lds + threadIdx.x, best, nNodes, nTris);
+                if (ltype == 0u) { v3 dl = best.loc - hitLoc; occ = h && (sqrtf(dot3(dl, dl)) < distToLight); }
+                else occ = h;
+            } else {
+                occ = occluded_fast<COUNT>(S, o, dirToLight, (int)ltype, hitLoc, distToLight, lds + threadIdx.x, nNodes, nTris);
+            }
+            if (!occ) { acc.x += pe.x; acc.y += pe.y; acc.z += pe.z; dirty = true; }
+        }
+        if (dirty) P.accum[slot] = make_float4(acc.x, acc.y, acc.z, 1.f);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        nRays += __shfl_down(nRays, off, 64);
+        if (COUNT) { nNodes += __shfl_down(nNodes, off, 64); nTris += __shfl_down(nTris, off, 64); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nRays) atomicAdd(&stats->rays_shadow, (unsigned long long)nRays);
+        if (COUNT && (nNodes | nTris)) {
+            atomicAdd(&stats->node_visits, (unsigned long long)nNodes);
+            atomicAdd(&stats->tri_tests, (unsigned long long)nTris);
+        }
+    }
+}
+
+// Image defaults the shader stores for pixels whose primary ray misses (shader.comp:299-301,534-536).
+__global__ __launch_bounds__(RT_BLOCK) void k_init_frame(FrameParams F, PathBuffers P, float4* imgAlbedo, float4* imgNormal, float4* imgDepth) {
+    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (slot >= P.nslots) return;
+    P.accum[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
+    int px, py;
+    slot_to_pixel(F, slot, &px, &py);
+    if (px < F.rx + F.rw && py < F.ry + F.rh && imgAlbedo) {
+        size_t pix = (size_t)py * F.width + px;
+        imgAlbedo[pix] = make_float4(0.f, 0.f, 0.f, 1.f);
+        imgNormal[pix] = make_float4(0.5f, 0.5f, 0.5f, 1.f);
+        imgDepth[pix] = make_float4(0.f, 0.f, 0.f, 1.f);
+    }
+}
+
+// shader.comp:533 — un-swizzle the tile-ordered accumulators into the row-major colour image.
+__global__ __launch_bounds__(RT_BLOCK) void k_finalize(FrameParams F, PathBuffers P, float4* imgColor) {
+    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (slot >= P.nslots) return;
+    int px, py;
+    slot_to_pixel(F, slot, &px, &py);
+    if (px < F.rx + F.rw && py < F.ry + F.rh) {
+        float4 c = P.accum[slot];
+        imgColor[(size_t)py * F.width + px] = make_float4(c.x, c.y, c.z, 1.f);
+    }
+}
+
+// rt_trace_rays: scatter caller rays into slots 0..n-1.
+__global__ __launch_bounds__(RT_BLOCK) void k_load_rays(PathBuffers P, const float* origins, const float* dirs, uint32_t n,
+                                                        uint32_t* queueOut, uint32_t* countOut) {
+    uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i < n) {
+        P.rayO[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.f);
+        P.rayD[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], 0.f);
+        queueOut[i] = i;
+    }
+    if (i == 0) *countOut = n;
+}
+
+}  // namespace rt
