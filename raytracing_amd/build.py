@@ -1,0 +1,33 @@
+"""Builds librt_core.so (HIP, gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "librt_core.so")
+SOURCES = ["rt_core.hip"]
+HEADERS = ["rt_kernels.hip.h", "rt_math.h", "rt_types.h", "rt_compact.h", "../../include/rt_core.h"]
+# -ffp-contract=off: the integrator's float sequence is part of the parity contract.
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-shared", "-fPIC"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

@@ -1,0 +1,194 @@
+// Host-side derivation of the compacted device layout (CNode / CTri / CShade) from the reference's
+// SSBO images (slots 0,1,3,4).  Runs once per scene upload, on the host, with the same float
+// operations the shader performs per ray (shader.comp:263-265, 348-350), so the kernels read values
+// bit-identical to what the reference recomputes on every test.  Compiled with -ffp-contract=off.
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "rt_types.h"
+
+namespace rt {
+
+struct CompactScene {
+    std::vector<CNode> nodes;
+    std::vector<CTri> tris;
+    std::vector<CShade> shade;
+    int32_t rootChild = -1;
+    float rootLo[3] = {0, 0, 0}, rootHi[3] = {0, 0, 0};
+    float sceneScale = 1.f;
+    bool boxesContainTris = true;   // false -> only traversalMode 1 is valid (mesh-local boxes vs world triangles)
+    uint32_t maxDepth = 0;
+};
+
+// vec3(M * vec4(v, w)), column-major, summed left to right (GLSL mat4*vec4).
+static inline f3 mul_point(const RefMat4& M, const f3& v, float w) {
+    f3 r;
+    r.x = M.m[0][0] * v.x + M.m[1][0] * v.y + M.m[2][0] * v.z + M.m[3][0] * w;
+    r.y = M.m[0][1] * v.x + M.m[1][1] * v.y + M.m[2][1] * v.z + M.m[3][1] * w;
+    r.z = M.m[0][2] * v.x + M.m[1][2] * v.y + M.m[2][2] * v.z + M.m[3][2] * w;
+    return r;
+}
+
+// Returns "" on success, else an error message (inconsistent buffers).
+static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts, const RefMat4* mats, uint64_t nMats,
+                                        uint64_t nMaterials, const RefNode* rnodes, uint64_t nNodes,
+                                        const RefTriangle* rtris, uint64_t nTris, CompactScene& out) {
+    if (nNodes == 0) return "BVH node buffer (slot 3) is empty";
+    if (nTris >= (1ull << 28)) return "too many triangles for the leaf encoding";
+    // ---- per-triangle world-space vertices + shading records ----
+    std::vector<f3> wv(nTris * 3);
+    out.shade.resize(nTris);
+    for (uint64_t i = 0; i < nTris; i++) {
+        const RefTriangle& t = rtris[i];
+        for (int k = 0; k < 3; k++)
+            if (t.indices[k] >= nVerts) return "triangle " + std::to_string(i) + ": vertex index out of range";
+        if (t.meshIndex >= nMats) return "triangle " + std::to_string(i) + ": meshIndex out of range";
+        if (t.materialIndex >= nMaterials) return "triangle " + std::to_string(i) + ": materialIndex out of range";
+        const RefMat4& M = mats[t.meshIndex];
+        for (int k = 0; k < 3; k++) wv[i * 3 + k] = mul_point(M, verts[t.indices[k]].position, 1.f);
+        CShade& s = out.shade[i];
+        const f3 P[3] = {t.p1, t.p2, t.p3};
+        float* dstP[3] = {s.a, s.b, s.c};
+        float* dstN[3] = {s.n1, s.n2, s.n3};
+        float* dstUV[3] = {s.uv1, s.uv2, s.uv3};
+        for (int k = 0; k < 3; k++) {
+            dstP[k][0] = P[k].x; dstP[k][1] = P[k].y; dstP[k][2] = P[k].z;
+            f3 n = mul_point(M, verts[t.indices[k]].normal, 0.f);
+            dstN[k][0] = n.x; dstN[k][1] = n.y; dstN[k][2] = n.z;
+            dstUV[k][0] = verts[t.indices[k]].texUV[0]; dstUV[k][1] = verts[t.indices[k]].texUV[1];
+        }
+        s.materialIndex = t.materialIndex;
+        s.i1 = t.indices[0]; s.i2 = t.indices[1]; s.i3 = t.indices[2];
+    }
+
+    // ---- scene scale (for the slack terms of traversalMode 0) ----
+    float scale = 0.f;
+    for (uint64_t i = 0; i < nTris * 3; i++) {
+        scale = std::max(scale, std::fabs(wv[i].x)); scale = std::max(scale, std::fabs(wv[i].y)); scale = std::max(scale, std::fabs(wv[i].z));
+    }
+    if (!(scale > 0.f) || !std::isfinite(scale)) scale = 1.f;
+    out.sceneScale = scale;
+    const float padAbs = 1e-5f * scale;
+
+    // ---- walk the reference tree in its own visit order (children.y before children.x) ----
+    out.nodes.clear(); out.tris.clear();
+    out.nodes.reserve(nNodes / 2 + 1); out.tris.reserve(nTris);
+    struct Bounds { float lo[3], hi[3]; };
+    auto emptyB = []() { Bounds b; for (int k = 0; k < 3; k++) { b.lo[k] = FLT_MAX; b.hi[k] = -FLT_MAX; } return b; };
+    auto grow = [](Bounds& b, const f3& p) {
+        b.lo[0] = std::min(b.lo[0], p.x); b.lo[1] = std::min(b.lo[1], p.y); b.lo[2] = std::min(b.lo[2], p.z);
+        b.hi[0] = std::max(b.hi[0], p.x); b.hi[1] = std::max(b.hi[1], p.y); b.hi[2] = std::max(b.hi[2], p.z);
+    };
+    auto merge = [](Bounds& b, const Bounds& o) {
+        for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); }
+    };
+
+    // emit a leaf: appends its triangles, returns the leaf code and its padded world bounds
+    auto emitLeaf = [&](const RefNode& n, Bounds& wb, std::string& err) -> int32_t {
+        uint32_t first = (uint32_t)out.tris.size(), cnt = 0;
+        wb = emptyB();
+        for (int k = 0; k < 4; k++) {
+            int32_t ti = n.children[k];
+            if (ti == -1) continue;
+            if (ti < 0 || (uint64_t)ti >= nTris) { err = "leaf references triangle out of range"; return 0; }
+            CTri c;
+            const f3 &a = wv[(uint64_t)ti * 3], &b = wv[(uint64_t)ti * 3 + 1], &cc = wv[(uint64_t)ti * 3 + 2];
+            c.v0[0] = a.x; c.v0[1] = a.y; c.v0[2] = a.z;
+            c.e1[0] = b.x - a.x; c.e1[1] = b.y - a.y; c.e1[2] = b.z - a.z;      // shader.comp:105
+            c.e2[0] = cc.x - a.x; c.e2[1] = cc.y - a.y; c.e2[2] = cc.z - a.z;   // shader.comp:106
+            c.refIndex = ti; c.pad[0] = c.pad[1] = 0;
+            out.tris.push_back(c);
+            grow(wb, a); grow(wb, b); grow(wb, cc);
+            cnt++;
+        }
+        return -(int32_t)(first * 8u + cnt) - 1;
+    };
+    auto padBox = [&](const Bounds& wb, float* lo, float* hi) {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = wb.lo[k] - (padAbs + 1e-5f * std::fabs(wb.lo[k]));
+            hi[k] = wb.hi[k] + (padAbs + 1e-5f * std::fabs(wb.hi[k]));
+        }
+    };
+
+    const RefNode& root = rnodes[0];
+    out.rootLo[0] = root.minLoc.x; out.rootLo[1] = root.minLoc.y; out.rootLo[2] = root.minLoc.z;
+    out.rootHi[0] = root.maxLoc.x; out.rootHi[1] = root.maxLoc.y; out.rootHi[2] = root.maxLoc.z;
+    out.boxesContainTris = true;
+    std::string err;
+    if (root.isLeaf == 1) {
+        Bounds wb;
+        out.rootChild = emitLeaf(root, wb, err);
+        if (!err.empty()) return err;
+        // a lone leaf root keeps the reference's inverted-infinite box, which every ray passes (Q2)
+        return "";
+    }
+
+    // Iterative DFS.  Frame state: 0 = fresh, 1 = children.y done, 2 = both done.
+    struct Frame { uint32_t ref; int32_t cidx; int state; Bounds wb; uint32_t depth; };
+    std::vector<Frame> st;
+    std::vector<uint8_t> seen(nNodes, 0);
+    auto newInternal = [&](uint32_t ref, uint32_t depth) -> int32_t {
+        CNode n; std::memset(&n, 0, sizeof n);
+        n.child0 = n.child1 = -1;  // empty leaf code (first 0, count 0)
+        for (int k = 0; k < 3; k++) { n.lo0[k] = n.lo1[k] = FLT_MAX; n.hi0[k] = n.hi1[k] = -FLT_MAX; }
+        out.nodes.push_back(n);
+        Frame f; f.ref = ref; f.cidx = (int32_t)out.nodes.size() - 1; f.state = 0; f.wb = emptyB(); f.depth = depth;
+        st.push_back(f);
+        out.maxDepth = std::max(out.maxDepth, depth);
+        return f.cidx;
+    };
+    seen[0] = 1;
+    out.rootChild = newInternal(0, 1);
+    while (!st.empty()) {
+        Frame& f = st.back();
+        if (f.state == 2) {
+            // finished: containment check of the reference box against the world bounds below it
+            const RefNode& rn = rnodes[f.ref];
+            const float rlo[3] = {rn.minLoc.x, rn.minLoc.y, rn.minLoc.z}, rhi[3] = {rn.maxLoc.x, rn.maxLoc.y, rn.maxLoc.z};
+            for (int k = 0; k < 3; k++)
+                if (f.wb.lo[k] <= f.wb.hi[k] && !(rlo[k] <= f.wb.lo[k] && f.wb.hi[k] <= rhi[k])) out.boxesContainTris = false;
+            Bounds done = f.wb;
+            st.pop_back();
+            if (!st.empty()) merge(st.back().wb, done);
+            continue;
+        }
+        int which = (f.state == 0) ? 1 : 0;   // children.y first (shader.comp:281-284 pushes x then y, pops y)
+        f.state++;
+        int32_t ci = rnodes[f.ref].children[which];
+        int32_t cidx = f.cidx;
+        uint32_t depth = f.depth;
+        if (ci == -1) continue;               // absent child: stays an empty leaf
+        if (ci < 0 || (uint64_t)ci >= nNodes) return "BVH child index out of range";
+        if (seen[ci]) return "BVH node referenced twice (not a tree)";
+        seen[ci] = 1;
+        const RefNode& cn = rnodes[ci];
+        if (cn.isLeaf == 1) {
+            Bounds wb;
+            int32_t code = emitLeaf(cn, wb, err);
+            if (!err.empty()) return err;
+            CNode& pn = out.nodes[cidx];
+            float* lo = which ? pn.lo1 : pn.lo0; float* hi = which ? pn.hi1 : pn.hi0;
+            if (wb.lo[0] <= wb.hi[0]) padBox(wb, lo, hi);
+            (which ? pn.child1 : pn.child0) = code;
+            merge(st.back().wb, wb);
+            out.maxDepth = std::max(out.maxDepth, depth + 1);
+        } else {
+            {
+                CNode& pn = out.nodes[cidx];
+                float* lo = which ? pn.lo1 : pn.lo0; float* hi = which ? pn.hi1 : pn.hi0;
+                lo[0] = cn.minLoc.x; lo[1] = cn.minLoc.y; lo[2] = cn.minLoc.z;
+                hi[0] = cn.maxLoc.x; hi[1] = cn.maxLoc.y; hi[2] = cn.maxLoc.z;
+            }
+            int32_t nidx = newInternal((uint32_t)ci, depth + 1);   // may reallocate out.nodes / st
+            (which ? out.nodes[cidx].child1 : out.nodes[cidx].child0) = nidx;
+        }
+    }
+    return "";
+}
+
+}  // namespace rt

@@ -1,0 +1,508 @@
+// librt_core.so — C ABI of the MI355X path-tracing core (include/rt_core.h).
+// Host orchestration of the wavefront kernels in rt_kernels.hip.h.  gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_core.h"
+#include "rt_compact.h"
+#include "rt_kernels.hip.h"
+
+using namespace rt;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct Texture { DevBuf data; uint32_t w = 0, h = 0; };
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // host copies of the reference buffers (slot uploads copy immediately; compaction is lazy)
+    std::vector<uint8_t> slotHost[6];
+    bool slotSet[6] = {false, false, false, false, false, false};
+    bool sceneDirty = true, lightsDirty = true, materialsDirty = true, texturesDirty = true;
+
+    // uniforms (shader.comp:85-102)
+    int32_t numLights = 0, hasSun = 0, samplesPerPixel = 1, maxBounces = 1;
+    float camPos[3] = {0, 0, 0}, camForward[3] = {0, 0, -1}, camRight[3] = {1, 0, 0}, camUp[3] = {0, 1, 0};
+    float aspect = 1.f, fov = 45.f;
+    float offset[2] = {0, 0};
+    int32_t traversalMode = 0, statsLevel = 1;
+
+    // device scene
+    DevBuf dNodes, dTris, dShade, dMaterials, dVertices, dLights, dTexDescs;
+    std::vector<Texture> textures;
+    CompactScene cs;
+    uint64_t nLights = 0, nMaterials = 0;
+
+    // images
+    uint32_t width = 0, height = 0;
+    DevBuf img[4];
+    DevBuf primTri, primHit;
+    bool primValid = false;
+
+    // path state
+    DevBuf rayO, rayD, rayS, hit, pend, accum, queues, shadowQueue, counters, dStats;
+    uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
+
+    hipEvent_t evA = nullptr, evB = nullptr;
+    rt_stats stats{};
+    int numCUs = 256;
+};
+
+namespace {
+
+thread_local std::string g_createErr;
+
+rt_status fail(rt_ctx* c, rt_status s, const std::string& m) { if (c) c->err = m; else g_createErr = m; return s; }
+
+#define HIPCHK(c, call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) return fail(c, RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+rt_status ensure(rt_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return RT_OK;
+    b.release();
+    if (bytes == 0) bytes = 16;
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return RT_OK;
+}
+
+rt_status upload(rt_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    rt_status s = ensure(c, b, bytes);
+    if (s) return s;
+    if (bytes) HIPCHK(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return RT_OK;
+}
+
+const size_t kRecordSize[6] = {80, 64, 80, 48, 128, 48};
+
+rt_status sync_scene(rt_ctx* c) {
+    for (int s = 0; s < 6; s++)
+        if (!c->slotSet[s]) return fail(c, RT_ERR_NOT_READY, "slot " + std::to_string(s) + " has not been uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->sceneDirty) {
+        const auto& V = c->slotHost[RT_SLOT_VERTICES]; const auto& M = c->slotHost[RT_SLOT_MESH_MATRICES];
+        const auto& N = c->slotHost[RT_SLOT_BVH_NODES]; const auto& T = c->slotHost[RT_SLOT_TRIANGLES];
+        std::string e = compact_scene((const RefVertex*)V.data(), V.size() / 80, (const RefMat4*)M.data(), M.size() / 64,
+                                      c->slotHost[RT_SLOT_MATERIALS].size() / 80, (const RefNode*)N.data(), N.size() / 48,
+                                      (const RefTriangle*)T.data(), T.size() / 128, c->cs);
+        if (!e.empty()) return fail(c, RT_ERR_SCENE, e);
+        rt_status s;
+        if ((s = upload(c, c->dNodes, c->cs.nodes.data(), c->cs.nodes.size() * sizeof(CNode)))) return s;
+        if ((s = upload(c, c->dTris, c->cs.tris.data(), c->cs.tris.size() * sizeof(CTri)))) return s;
+        if ((s = upload(c, c->dShade, c->cs.shade.data(), c->cs.shade.size() * sizeof(CShade)))) return s;
+        if ((s = upload(c, c->dVertices, V.data(), V.size()))) return s;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->sceneDirty = false;
+    }
+    if (c->materialsDirty) {
+        const auto& M = c->slotHost[RT_SLOT_MATERIALS];
+        // texture handles must name textures of this context
+        for (size_t i = 0; i < M.size() / 80; i++) {
+            const RefMaterial* m = (const RefMaterial*)M.data() + i;
+            if ((m->hasBaseTexture == 1 && (m->baseColorTexture == 0 || m->baseColorTexture > c->textures.size())) ||
+                (m->hasNormalTexture == 1 && (m->normalTexture == 0 || m->normalTexture > c->textures.size())) ||
+                (m->hasMetallicRoughnessTexture == 1 && (m->metallicRoughnessTexture == 0 || m->metallicRoughnessTexture > c->textures.size())))
+                return fail(c, RT_ERR_SCENE, "material " + std::to_string(i) + " names a texture handle rt_create_texture did not return");
+        }
+        rt_status s = upload(c, c->dMaterials, M.data(), M.size());
+        if (s) return s;
+        c->nMaterials = M.size() / 80;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->materialsDirty = false;
+    }
+    if (c->lightsDirty) {
+        const auto& L = c->slotHost[RT_SLOT_LIGHTS];
+        rt_status s = upload(c, c->dLights, L.data(), L.size());
+        if (s) return s;
+        c->nLights = L.size() / 48;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->lightsDirty = false;
+    }
+    if (c->texturesDirty) {
+        std::vector<TexDesc> d(c->textures.size());
+        for (size_t i = 0; i < d.size(); i++) { d[i].rgba8 = (const uint8_t*)c->textures[i].data.p; d[i].width = c->textures[i].w; d[i].height = c->textures[i].h; }
+        rt_status s = upload(c, c->dTexDescs, d.data(), d.size() * sizeof(TexDesc));
+        if (s) return s;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->texturesDirty = false;
+    }
+    return RT_OK;
+}
+
+SceneView make_view(rt_ctx* c, bool exact) {
+    SceneView S;
+    std::memset(&S, 0, sizeof S);
+    S.nodes = (const CNode*)c->dNodes.p; S.tris = (const CTri*)c->dTris.p; S.shade = (const CShade*)c->dShade.p;
+    S.materials = (const RefMaterial*)c->dMaterials.p; S.vertices = (const RefVertex*)c->dVertices.p;
+    S.lights = (const RefLight*)c->dLights.p; S.textures = (const TexDesc*)c->dTexDescs.p;
+    S.n_textures = (uint32_t)c->textures.size();
+    S.rootChild = c->cs.rootChild;
+    for (int k = 0; k < 3; k++) { S.rootLo[k] = c->cs.rootLo[k]; S.rootHi[k] = c->cs.rootHi[k]; }
+    S.cullAbs = 1e-5f * c->cs.sceneScale;
+    S.exactMode = exact ? 1 : 0;
+    return S;
+}
+
+bool use_exact(rt_ctx* c) { return c->traversalMode == 1 || !c->cs.boxesContainTris; }
+
+rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t nLights, uint32_t maxBounces) {
+    rt_status s;
+    size_t n = nslots;
+    if ((s = ensure(c, c->rayO, n * 16))) return s;
+    if ((s = ensure(c, c->rayD, n * 16))) return s;
+    if ((s = ensure(c, c->rayS, n * 16))) return s;
+    if ((s = ensure(c, c->hit, n * 16))) return s;
+    if ((s = ensure(c, c->pend, n * 16 * (nLights ? nLights : 1)))) return s;
+    if ((s = ensure(c, c->accum, n * 16))) return s;
+    if ((s = ensure(c, c->queues, n * 4 * 2))) return s;
+    if ((s = ensure(c, c->shadowQueue, n * 4))) return s;
+    if ((s = ensure(c, c->counters, (size_t)(2 * (maxBounces + 1)) * 4))) return s;
+    if ((s = ensure(c, c->dStats, sizeof(DeviceStats)))) return s;
+    return RT_OK;
+}
+
+PathBuffers make_paths(rt_ctx* c, uint32_t nslots) {
+    PathBuffers P;
+    P.rayO = (float4*)c->rayO.p; P.rayD = (float4*)c->rayD.p; P.rayS = (float4*)c->rayS.p; P.hit = (float4*)c->hit.p;
+    P.pend = (float4*)c->pend.p; P.accum = (float4*)c->accum.p; P.queues = (uint32_t*)c->queues.p;
+    P.shadowQueue = (uint32_t*)c->shadowQueue.p; P.counters = (uint32_t*)c->counters.p; P.nslots = nslots;
+    return P;
+}
+
+template <typename... Args>
+void launch_extend(bool exact, bool count, dim3 g, hipStream_t st, Args... a) {
+    if (exact) { if (count) k_extend<true, true><<<g, RT_BLOCK, 0, st>>>(a...); else k_extend<true, false><<<g, RT_BLOCK, 0, st>>>(a...); }
+    else { if (count) k_extend<false, true><<<g, RT_BLOCK, 0, st>>>(a...); else k_extend<false, false><<<g, RT_BLOCK, 0, st>>>(a...); }
+}
+template <typename... Args>
+void launch_shadow(bool exact, bool count, dim3 g, hipStream_t st, Args... a) {
+    if (exact) { if (count) k_shadow<true, true><<<g, RT_BLOCK, 0, st>>>(a...); else k_shadow<true, false><<<g, RT_BLOCK, 0, st>>>(a...); }
+    else { if (count) k_shadow<false, true><<<g, RT_BLOCK, 0, st>>>(a...); else k_shadow<false, false><<<g, RT_BLOCK, 0, st>>>(a...); }
+}
+
+rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint32_t r0, uint32_t r1) {
+    if (!c) return RT_ERR_INVALID;
+    if (c->width == 0 || c->height == 0) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
+    if (w == 0 || h == 0 || x + w > c->width || y + h > c->height) return fail(c, RT_ERR_INVALID, "region outside the image");
+    if (c->samplesPerPixel < 1 || c->maxBounces < 0) return fail(c, RT_ERR_INVALID, "samplesPerPixel must be >= 1 and maxBounces >= 0");
+    if (r0 > r1 || r1 > (uint32_t)c->samplesPerPixel) return fail(c, RT_ERR_INVALID, "sample range outside [0, samplesPerPixel]");
+    rt_status s = sync_scene(c);
+    if (s) return s;
+    if ((uint64_t)c->numLights > c->nLights) return fail(c, RT_ERR_INVALID, "numLights exceeds the light buffer (slot 5)");
+    if (c->numLights > RT_MAX_LIGHTS) return fail(c, RT_ERR_INVALID, "numLights exceeds RT_MAX_LIGHTS");
+    auto t0 = std::chrono::steady_clock::now();
+
+    FrameParams F;
+    std::memset(&F, 0, sizeof F);
+    F.width = (int)c->width; F.height = (int)c->height;
+    F.rx = (int)x; F.ry = (int)y; F.rw = (int)w; F.rh = (int)h;
+    F.tilesX = (int)((w + 7) / 8);
+    uint32_t tilesY = (h + 7) / 8;
+    uint32_t nslots = (uint32_t)F.tilesX * tilesY * 64u;
+    F.numLights = c->numLights < 0 ? 0 : c->numLights; F.hasSun = c->hasSun;
+    for (int k = 0; k < 3; k++) { F.camPos[k] = c->camPos[k]; F.camForward[k] = c->camForward[k]; F.camRight[k] = c->camRight[k]; F.camUp[k] = c->camUp[k]; }
+    F.aspect = c->aspect;
+    F.tanHalfFov = tanf((c->fov * 0.017453292519943295f) / 2.0f);   // tan(radians(fov) / 2.0), shader.comp:321
+    F.samplesPerPixel = c->samplesPerPixel; F.maxBounces = c->maxBounces;
+    F.gridN = (int)ceilf(sqrtf((float)c->samplesPerPixel));            // shader.comp:309-310
+    F.initialStrength = 1.f / (float)c->samplesPerPixel;               // shader.comp:307
+    F.strengthCutoff = .01f / (float)c->samplesPerPixel;               // shader.comp:306
+
+    const uint32_t maxB = (uint32_t)c->maxBounces;
+    if ((s = ensure_paths(c, nslots, (uint32_t)F.numLights, maxB))) return s;
+    PathBuffers P = make_paths(c, nslots);
+    const bool exact = use_exact(c);
+    const bool count = c->statsLevel >= 2;
+    SceneView S = make_view(c, exact);
+    DeviceStats* dst = (DeviceStats*)c->dStats.p;
+    hipStream_t st = c->stream;
+
+    HIPCHK(c, hipMemsetAsync(dst, 0, sizeof(DeviceStats), st));
+    // colour image: zero outside the region
+    HIPCHK(c, hipMemsetAsync(c->img[0].p, 0, (size_t)c->width * c->height * 16, st));
+    const bool aov = (r0 == 0);
+    float4* iAlb = aov ? (float4*)c->img[1].p : nullptr;
+    float4* iNor = aov ? (float4*)c->img[2].p : nullptr;
+    float4* iDep = aov ? (float4*)c->img[3].p : nullptr;
+    int32_t* pTri = aov ? (int32_t*)c->primTri.p : nullptr;
+    float* pHit = aov ? (float*)c->primHit.p : nullptr;
+    if (aov) {
+        for (int i = 1; i < 4; i++) HIPCHK(c, hipMemsetAsync(c->img[i].p, 0, (size_t)c->width * c->height * 16, st));
+        HIPCHK(c, hipMemsetAsync(c->primTri.p, 0xFF, (size_t)c->width * c->height * 4, st));
+        HIPCHK(c, hipMemsetAsync(c->primHit.p, 0, (size_t)c->width * c->height * 12, st));
+    }
+    const uint32_t slotBlocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
+    k_init_frame<<<slotBlocks, RT_BLOCK, 0, st>>>(F, P, iAlb, iNor, iDep);
+
+    const uint32_t persistent = (uint32_t)c->numCUs * 8u;
+    const uint32_t traceBlocks = slotBlocks < persistent ? slotBlocks : persistent;
+    uint32_t* qcount = P.counters;
+    uint32_t* scount = P.counters + (maxB + 1);
+    float msExtend = 0.f, msShade = 0.f, msShadow = 0.f;
+    const bool timeKernels = c->statsLevel >= 1;
+    uint64_t nExt = 0, nSh = 0;
+
+    for (uint32_t r = r0; r < r1; r++) {
+        HIPCHK(c, hipMemsetAsync(P.counters, 0, (size_t)(2 * (maxB + 1)) * 4, st));
+        k_raygen<<<slotBlocks, RT_BLOCK, 0, st>>>(F, P, (int)r, P.queues, qcount);
+        for (uint32_t b = 0; b < maxB; b++) {
+            uint32_t* qin = P.queues + (size_t)(b & 1) * nslots;
+            uint32_t* qout = P.queues + (size_t)((b + 1) & 1) * nslots;
+            launch_extend(exact, count, dim3(traceBlocks), st, S, P, (const uint32_t*)qin, (const uint32_t*)(qcount + b), b == 0 ? 1 : 0, dst);
+            k_shade<<<traceBlocks, RT_BLOCK, 0, st>>>(S, F, P, (const uint32_t*)qin, (const uint32_t*)(qcount + b), qout, qcount + b + 1,
+                                                       scount + b, (int)r, (int)b, r == 0 ? iAlb : nullptr, r == 0 ? iNor : nullptr,
+                                                       r == 0 ? iDep : nullptr, r == 0 ? pTri : nullptr, r == 0 ? pHit : nullptr, dst);
+            if (F.numLights > 0)
+                launch_shadow(exact, count, dim3(traceBlocks), st, S, F, P, (const uint32_t*)(scount + b), dst);
+            nExt++; nSh++;
+        }
+    }
+    k_finalize<<<slotBlocks, RT_BLOCK, 0, st>>>(F, P, (float4*)c->img[0].p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    (void)timeKernels; (void)msExtend; (void)msShade; (void)msShadow;
+
+    DeviceStats hs;
+    HIPCHK(c, hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost));
+    auto t1 = std::chrono::steady_clock::now();
+    std::memset(&c->stats, 0, sizeof c->stats);
+    c->stats.rays_primary = hs.rays_primary; c->stats.rays_bounce = hs.rays_bounce; c->stats.rays_shadow = hs.rays_shadow;
+    c->stats.rays_shadow_skipped = hs.rays_shadow_skipped; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
+    c->stats.ms_total = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    c->stats.launches_extend = nExt; c->stats.launches_shadow = F.numLights > 0 ? nSh : 0;
+    c->primValid = aov;
+    return RT_OK;
+}
+
+bool name_is(const char* a, const char* b) { return std::strcmp(a, b) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+rt_status rt_create(rt_ctx** out, const rt_config* cfg) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int dev = cfg ? cfg->device : 0;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available (librt_core has no CPU fallback)");
+    if (dev < 0 || dev >= ndev) return fail(nullptr, RT_ERR_NO_DEVICE, "device ordinal out of range");
+    if (hipSetDevice(dev) != hipSuccess) return fail(nullptr, RT_ERR_NO_DEVICE, "hipSetDevice failed");
+    rt_ctx* c = new rt_ctx();
+    c->device = dev;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(nullptr, RT_ERR_HIP, "hipStreamCreate failed"); }
+    (void)hipEventCreate(&c->evA); (void)hipEventCreate(&c->evB);
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->dNodes, &c->dTris, &c->dShade, &c->dMaterials, &c->dVertices, &c->dLights, &c->dTexDescs,
+                      &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->rayO, &c->rayD, &c->rayS,
+                      &c->hit, &c->pend, &c->accum, &c->queues, &c->shadowQueue, &c->counters, &c->dStats};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& t : c->textures) t.data.release();
+    if (c->evA) (void)hipEventDestroy(c->evA);
+    if (c->evB) (void)hipEventDestroy(c->evB);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_createErr.c_str(); }
+
+rt_status rt_upload_buffer(rt_ctx* c, uint32_t slot, const void* data, uint64_t bytes) {
+    if (!c) return RT_ERR_INVALID;
+    if (slot > 5) return fail(c, RT_ERR_INVALID, "slot must be 0..5");
+    if (bytes && !data) return fail(c, RT_ERR_INVALID, "data is NULL");
+    if (bytes % kRecordSize[slot]) return fail(c, RT_ERR_INVALID, "size is not a multiple of the slot's record size");
+    c->slotHost[slot].assign((const uint8_t*)data, (const uint8_t*)data + bytes);
+    c->slotSet[slot] = true;
+    if (slot == RT_SLOT_LIGHTS) c->lightsDirty = true;
+    else if (slot == RT_SLOT_MATERIALS) { c->materialsDirty = true; c->sceneDirty = true; }
+    else c->sceneDirty = true;
+    return RT_OK;
+}
+
+rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
+    if (!c || !name) return RT_ERR_INVALID;
+    if (name_is(name, "numLights")) c->numLights = v;
+    else if (name_is(name, "hasSun")) c->hasSun = v;
+    else if (name_is(name, "samplesPerPixel")) c->samplesPerPixel = v;
+    else if (name_is(name, "maxBounces")) c->maxBounces = v;
+    else if (name_is(name, "traversalMode")) c->traversalMode = v;
+    else if (name_is(name, "statsLevel")) c->statsLevel = v;
+    return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
+}
+rt_status rt_set_float(rt_ctx* c, const char* name, float v) {
+    if (!c || !name) return RT_ERR_INVALID;
+    if (name_is(name, "aspect")) c->aspect = v;
+    else if (name_is(name, "fov")) c->fov = v;
+    return RT_OK;
+}
+rt_status rt_set_vec2(rt_ctx* c, const char* name, const float v[2]) {
+    if (!c || !name || !v) return RT_ERR_INVALID;
+    if (name_is(name, "offset")) { c->offset[0] = v[0]; c->offset[1] = v[1]; }   // tile origin: scheduling only (main.cpp:126-139)
+    return RT_OK;
+}
+rt_status rt_set_vec3(rt_ctx* c, const char* name, const float v[3]) {
+    if (!c || !name || !v) return RT_ERR_INVALID;
+    float* dst = nullptr;
+    if (name_is(name, "camPos")) dst = c->camPos;
+    else if (name_is(name, "camForward")) dst = c->camForward;
+    else if (name_is(name, "camRight")) dst = c->camRight;
+    else if (name_is(name, "camUp")) dst = c->camUp;
+    if (dst) { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; }
+    return RT_OK;
+}
+rt_status rt_set_vec4(rt_ctx* c, const char* name, const float v[4]) { return (!c || !name || !v) ? RT_ERR_INVALID : RT_OK; }
+rt_status rt_set_mat4(rt_ctx* c, const char* name, const float m[16]) { return (!c || !name || !m) ? RT_ERR_INVALID : RT_OK; }
+
+rt_status rt_resize(rt_ctx* c, uint32_t w, uint32_t h) {
+    if (!c) return RT_ERR_INVALID;
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(c, RT_ERR_INVALID, "bad image size");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t n = (size_t)w * h;
+    rt_status s;
+    for (int i = 0; i < 4; i++) {
+        if ((s = ensure(c, c->img[i], n * 16))) return s;
+        HIPCHK(c, hipMemsetAsync(c->img[i].p, 0, n * 16, c->stream));
+    }
+    if ((s = ensure(c, c->primTri, n * 4))) return s;
+    if ((s = ensure(c, c->primHit, n * 12))) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->width = w; c->height = h; c->primValid = false;
+    return RT_OK;
+}
+
+rt_status rt_create_texture(rt_ctx* c, const uint8_t* rgba8, uint32_t w, uint32_t h, uint64_t* handle_out) {
+    if (!c || !rgba8 || !handle_out || w == 0 || h == 0) return c ? fail(c, RT_ERR_INVALID, "bad texture arguments") : RT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    Texture t; t.w = w; t.h = h;
+    rt_status s = upload(c, t.data, rgba8, (size_t)w * h * 4);
+    if (s) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->textures.push_back(t);
+    c->texturesDirty = true; c->materialsDirty = true;
+    *handle_out = (uint64_t)c->textures.size();
+    return RT_OK;
+}
+
+rt_status rt_render_frame(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    return render_region(c, 0, 0, c->width, c->height, 0, (uint32_t)(c->samplesPerPixel > 0 ? c->samplesPerPixel : 0));
+}
+rt_status rt_render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint32_t r0, uint32_t r1) {
+    return render_region(c, x, y, w, h, r0, r1);
+}
+
+rt_status rt_read_image(rt_ctx* c, uint32_t image, float* dst) {
+    if (!c) return RT_ERR_INVALID;
+    if (image > 3 || !dst) return fail(c, RT_ERR_INVALID, "image must be 0..3 and dst non-NULL");
+    if (!c->img[image].p) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, c->img[image].p, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+rt_status rt_write_image(rt_ctx* c, uint32_t image, const float* src) {
+    if (!c) return RT_ERR_INVALID;
+    if (image > 3 || !src) return fail(c, RT_ERR_INVALID, "image must be 0..3 and src non-NULL");
+    if (!c->img[image].p) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(c->img[image].p, src, (size_t)c->width * c->height * 16, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+rt_status rt_image_device_ptr(rt_ctx* c, uint32_t image, void** p) {
+    if (!c) return RT_ERR_INVALID;
+    if (image > 3 || !p) return fail(c, RT_ERR_INVALID, "image must be 0..3");
+    if (!c->img[image].p) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
+    *p = c->img[image].p;
+    return RT_OK;
+}
+
+rt_status rt_get_stats(rt_ctx* c, rt_stats* out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    *out = c->stats;
+    return RT_OK;
+}
+
+rt_status rt_read_primary_hits(rt_ctx* c, int32_t* tri, float* hits) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->primValid) return fail(c, RT_ERR_NOT_READY, "no render containing sample 0 has run");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t n = (size_t)c->width * c->height;
+    if (tri) HIPCHK(c, hipMemcpy(tri, c->primTri.p, n * 4, hipMemcpyDeviceToHost));
+    if (hits) HIPCHK(c, hipMemcpy(hits, c->primHit.p, n * 12, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint64_t n, int32_t* tri, float* hits) {
+    if (!c) return RT_ERR_INVALID;
+    if (!origins || !dirs || !tri) return fail(c, RT_ERR_INVALID, "NULL argument");
+    if (n == 0) return RT_OK;
+    if (n > (1ull << 28)) return fail(c, RT_ERR_INVALID, "too many rays in one call");
+    // lights are not needed for a closest-hit query
+    bool hadLights = c->slotSet[RT_SLOT_LIGHTS];
+    if (!hadLights) { c->slotSet[RT_SLOT_LIGHTS] = true; c->lightsDirty = true; }
+    rt_status s = sync_scene(c);
+    if (!hadLights) c->slotSet[RT_SLOT_LIGHTS] = false;
+    if (s) return s;
+    uint32_t nslots = (uint32_t)((n + 63) / 64 * 64);
+    if ((s = ensure_paths(c, nslots, 1, 1))) return s;
+    PathBuffers P = make_paths(c, nslots);
+    const bool exact = use_exact(c);
+    const bool count = c->statsLevel >= 2;
+    SceneView S = make_view(c, exact);
+    DevBuf dO, dD;
+    if ((s = upload(c, dO, origins, n * 12))) return s;
+    if ((s = upload(c, dD, dirs, n * 12))) { dO.release(); return s; }
+    hipStream_t st = c->stream;
+    DeviceStats* dst = (DeviceStats*)c->dStats.p;
+    (void)hipMemsetAsync(dst, 0, sizeof(DeviceStats), st);
+    uint32_t blocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
+    k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, (const float*)dO.p, (const float*)dD.p, (uint32_t)n, P.queues, P.counters);
+    uint32_t persistent = (uint32_t)c->numCUs * 8u;
+    launch_extend(exact, count, dim3(blocks < persistent ? blocks : persistent), st, S, P, (const uint32_t*)P.queues,
+                  (const uint32_t*)P.counters, 1, dst);
+    hipError_t e = hipStreamSynchronize(st);
+    std::vector<float> h4(n * 4);
+    if (e == hipSuccess) e = hipMemcpy(h4.data(), P.hit, n * 16, hipMemcpyDeviceToHost);
+    DeviceStats hs; std::memset(&hs, 0, sizeof hs);
+    if (e == hipSuccess) e = hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost);
+    dO.release(); dD.release();
+    if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("rt_trace_rays: ") + hipGetErrorString(e));
+    for (uint64_t i = 0; i < n; i++) {
+        int32_t id; std::memcpy(&id, &h4[i * 4 + 3], 4);
+        tri[i] = id;
+        if (hits) { hits[i * 3] = h4[i * 4]; hits[i * 3 + 1] = h4[i * 4 + 1]; hits[i * 3 + 2] = h4[i * 4 + 2]; }
+    }
+    std::memset(&c->stats, 0, sizeof c->stats);
+    c->stats.rays_primary = hs.rays_primary; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
+    return RT_OK;
+}
+
+}  // extern "C"

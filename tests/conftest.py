@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODELS = os.path.join(ROOT, "tests", "golden", "models")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def models_root():
+    return MODELS
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import ref
+    ref.build()
+    return ref
