@@ -71,7 +71,8 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * camUp, aspect, fov, samplesPerPixel, maxBounces, offset.  Unknown names (projection, invProj, view,
  * invView, time ...) are accepted and ignored, as glGetUniformLocation == -1 is in GL.
  * Extension names (no reference counterpart): traversalMode (0 = culled/ordered, 1 = reference-order
- * exhaustive), samplesPerPass. */
+ * exhaustive), timeKernels (1 = HIP-event timing per kernel class into rt_stats), countVisits (1 = run the
+ * instrumented traversal kernels that count node visits / triangle tests). */
 rt_status rt_set_int(rt_ctx* ctx, const char* name, int32_t v);
 rt_status rt_set_float(rt_ctx* ctx, const char* name, float v);
 rt_status rt_set_vec2(rt_ctx* ctx, const char* name, const float v[2]);
@@ -112,13 +113,16 @@ typedef struct rt_stats {
     uint64_t rays_bounce;      /* lineCast calls at bounce > 0                                 */
     uint64_t rays_shadow;      /* shadow lineCast calls actually traced                        */
     uint64_t rays_shadow_skipped; /* shadow casts the reference issues whose result cannot matter (N.L <= 0) */
-    uint64_t node_visits;      /* BVH node records fetched (only when statsLevel >= 2)         */
-    uint64_t tri_tests;        /* ray-triangle tests executed (only when statsLevel >= 2)      */
+    uint64_t node_visits;      /* closest-hit kernel: 64-byte node records fetched   (countVisits = 1) */
+    uint64_t tri_tests;        /* closest-hit kernel: 48-byte triangle records tested (countVisits = 1) */
+    uint64_t shadow_node_visits; /* same two counters for the shadow kernel */
+    uint64_t shadow_tri_tests;
     double   ms_total;         /* wall time of the render call, host clock                     */
-    double   ms_extend;        /* summed HIP-event time of the closest-hit kernels             */
+    double   ms_extend;        /* summed HIP-event time of the closest-hit kernels (timeKernels = 1) */
     double   ms_shade;         /* ... of the shading kernels                                   */
     double   ms_shadow;        /* ... of the shadow (any-hit) kernels                          */
     uint64_t launches_extend;  /* kernel launches behind ms_extend                             */
+    uint64_t launches_shade;
     uint64_t launches_shadow;
 } rt_stats;
 rt_status rt_get_stats(rt_ctx* ctx, rt_stats* out);

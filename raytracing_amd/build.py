@@ -5,8 +5,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "librt_core.so")
-SOURCES = ["rt_core.hip"]
-HEADERS = ["rt_kernels.hip.h", "rt_math.h", "rt_types.h", "rt_compact.h", "../../include/rt_core.h"]
+SOURCES = ["rt_core.hip", "host/rt_host.cpp"]
+HEADERS = ["rt_kernels.hip.h", "rt_math.h", "rt_types.h", "rt_compact.h", "../../include/rt_core.h",
+           "../../include/rt_host.h", "host/rt_host.hpp", "host/bvh_build.h", "host/json.h", "host/png.h"]
 # -ffp-contract=off: the integrator's float sequence is part of the parity contract.
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-shared", "-fPIC"]
 
@@ -22,7 +23,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

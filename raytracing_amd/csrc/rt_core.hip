@@ -40,7 +40,7 @@ struct rt_ctx {
     float camPos[3] = {0, 0, 0}, camForward[3] = {0, 0, -1}, camRight[3] = {1, 0, 0}, camUp[3] = {0, 1, 0};
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
-    int32_t traversalMode = 0, statsLevel = 1;
+    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0;
 
     // device scene
     DevBuf dNodes, dTris, dShade, dMaterials, dVertices, dLights, dTexDescs;
@@ -58,7 +58,8 @@ struct rt_ctx {
     DevBuf rayO, rayD, rayS, hit, pend, accum, queues, shadowQueue, counters, dStats;
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
 
-    hipEvent_t evA = nullptr, evB = nullptr;
+    struct EvPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; bool used = false; };
+    std::vector<EvPair> evRing;
     rt_stats stats{};
     int numCUs = 256;
 };
@@ -230,7 +231,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     if ((s = ensure_paths(c, nslots, (uint32_t)F.numLights, maxB))) return s;
     PathBuffers P = make_paths(c, nslots);
     const bool exact = use_exact(c);
-    const bool count = c->statsLevel >= 2;
+    const bool count = c->countVisits != 0;
     SceneView S = make_view(c, exact);
     DeviceStats* dst = (DeviceStats*)c->dStats.p;
     hipStream_t st = c->stream;
@@ -256,9 +257,32 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint32_t traceBlocks = slotBlocks < persistent ? slotBlocks : persistent;
     uint32_t* qcount = P.counters;
     uint32_t* scount = P.counters + (maxB + 1);
-    float msExtend = 0.f, msShade = 0.f, msShadow = 0.f;
-    const bool timeKernels = c->statsLevel >= 1;
-    uint64_t nExt = 0, nSh = 0;
+    // Optional per-kernel-class timing with HIP events on the launch stream (ring of pairs, drained lazily).
+    const bool timeKernels = c->timeKernels != 0;
+    double msAcc[3] = {0.0, 0.0, 0.0};
+    uint64_t nLaunch[3] = {0, 0, 0};
+    size_t evIdx = 0;
+    if (timeKernels && c->evRing.empty()) {
+        c->evRing.resize(1024);
+        for (auto& e : c->evRing) { HIPCHK(c, hipEventCreate(&e.a)); HIPCHK(c, hipEventCreate(&e.b)); }
+    }
+    auto evDrain = [&](rt_ctx::EvPair& e) {
+        if (!e.used) return;
+        float ms = 0.f;
+        (void)hipEventSynchronize(e.b);
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) msAcc[e.kind] += ms;
+        e.used = false;
+    };
+    auto evBegin = [&](int kind) -> rt_ctx::EvPair* {
+        nLaunch[kind]++;
+        if (!timeKernels) return nullptr;
+        rt_ctx::EvPair& e = c->evRing[evIdx++ % c->evRing.size()];
+        evDrain(e);
+        e.kind = kind; e.used = true;
+        (void)hipEventRecord(e.a, st);
+        return &e;
+    };
+    auto evEnd = [&](rt_ctx::EvPair* e) { if (e) (void)hipEventRecord(e->b, st); };
 
     for (uint32_t r = r0; r < r1; r++) {
         HIPCHK(c, hipMemsetAsync(P.counters, 0, (size_t)(2 * (maxB + 1)) * 4, st));
@@ -266,19 +290,25 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         for (uint32_t b = 0; b < maxB; b++) {
             uint32_t* qin = P.queues + (size_t)(b & 1) * nslots;
             uint32_t* qout = P.queues + (size_t)((b + 1) & 1) * nslots;
+            rt_ctx::EvPair* e = evBegin(0);
             launch_extend(exact, count, dim3(traceBlocks), st, S, P, (const uint32_t*)qin, (const uint32_t*)(qcount + b), b == 0 ? 1 : 0, dst);
+            evEnd(e);
+            e = evBegin(1);
             k_shade<<<traceBlocks, RT_BLOCK, 0, st>>>(S, F, P, (const uint32_t*)qin, (const uint32_t*)(qcount + b), qout, qcount + b + 1,
                                                        scount + b, (int)r, (int)b, r == 0 ? iAlb : nullptr, r == 0 ? iNor : nullptr,
                                                        r == 0 ? iDep : nullptr, r == 0 ? pTri : nullptr, r == 0 ? pHit : nullptr, dst);
-            if (F.numLights > 0)
+            evEnd(e);
+            if (F.numLights > 0) {
+                e = evBegin(2);
                 launch_shadow(exact, count, dim3(traceBlocks), st, S, F, P, (const uint32_t*)(scount + b), dst);
-            nExt++; nSh++;
+                evEnd(e);
+            }
         }
     }
     k_finalize<<<slotBlocks, RT_BLOCK, 0, st>>>(F, P, (float4*)c->img[0].p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
-    (void)timeKernels; (void)msExtend; (void)msShade; (void)msShadow;
+    if (timeKernels) for (auto& e : c->evRing) evDrain(e);
 
     DeviceStats hs;
     HIPCHK(c, hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost));
@@ -287,7 +317,9 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.rays_primary = hs.rays_primary; c->stats.rays_bounce = hs.rays_bounce; c->stats.rays_shadow = hs.rays_shadow;
     c->stats.rays_shadow_skipped = hs.rays_shadow_skipped; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
     c->stats.ms_total = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    c->stats.launches_extend = nExt; c->stats.launches_shadow = F.numLights > 0 ? nSh : 0;
+    c->stats.shadow_node_visits = hs.shadow_node_visits; c->stats.shadow_tri_tests = hs.shadow_tri_tests;
+    c->stats.ms_extend = msAcc[0]; c->stats.ms_shade = msAcc[1]; c->stats.ms_shadow = msAcc[2];
+    c->stats.launches_extend = nLaunch[0]; c->stats.launches_shade = nLaunch[1]; c->stats.launches_shadow = nLaunch[2];
     c->primValid = aov;
     return RT_OK;
 }
@@ -312,7 +344,6 @@ rt_status rt_create(rt_ctx** out, const rt_config* cfg) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(nullptr, RT_ERR_HIP, "hipStreamCreate failed"); }
-    (void)hipEventCreate(&c->evA); (void)hipEventCreate(&c->evB);
     *out = c;
     return RT_OK;
 }
@@ -326,8 +357,7 @@ void rt_destroy(rt_ctx* c) {
                       &c->hit, &c->pend, &c->accum, &c->queues, &c->shadowQueue, &c->counters, &c->dStats};
     for (DevBuf* b : bufs) b->release();
     for (auto& t : c->textures) t.data.release();
-    if (c->evA) (void)hipEventDestroy(c->evA);
-    if (c->evB) (void)hipEventDestroy(c->evB);
+    for (auto& e : c->evRing) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -354,7 +384,8 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "samplesPerPixel")) c->samplesPerPixel = v;
     else if (name_is(name, "maxBounces")) c->maxBounces = v;
     else if (name_is(name, "traversalMode")) c->traversalMode = v;
-    else if (name_is(name, "statsLevel")) c->statsLevel = v;
+    else if (name_is(name, "timeKernels")) c->timeKernels = v;
+    else if (name_is(name, "countVisits")) c->countVisits = v;
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
 }
 rt_status rt_set_float(rt_ctx* c, const char* name, float v) {
@@ -475,7 +506,7 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     if ((s = ensure_paths(c, nslots, 1, 1))) return s;
     PathBuffers P = make_paths(c, nslots);
     const bool exact = use_exact(c);
-    const bool count = c->statsLevel >= 2;
+    const bool count = c->countVisits != 0;
     SceneView S = make_view(c, exact);
     DevBuf dO, dD;
     if ((s = upload(c, dO, origins, n * 12))) return s;

@@ -603,8 +603,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
     if ((threadIdx.x & 63) == 0) {
         if (nRays) atomicAdd(&stats->rays_shadow, (unsigned long long)nRays);
         if (COUNT && (nNodes | nTris)) {
-            atomicAdd(&stats->node_visits, (unsigned long long)nNodes);
-            atomicAdd(&stats->tri_tests, (unsigned long long)nTris);
+            atomicAdd(&stats->shadow_node_visits, (unsigned long long)nNodes);
+            atomicAdd(&stats->shadow_tri_tests, (unsigned long long)nTris);
         }
     }
 }

@@ -128,7 +128,8 @@ struct FrameParams {
 
 struct DeviceStats {
     unsigned long long rays_primary, rays_bounce, rays_shadow, rays_shadow_skipped;
-    unsigned long long node_visits, tri_tests;
+    unsigned long long node_visits, tri_tests;                 // closest-hit (k_extend) traversal
+    unsigned long long shadow_node_visits, shadow_tri_tests;   // shadow (k_shadow) traversal
 };
 
 }  // namespace rt

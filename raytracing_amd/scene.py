@@ -1,0 +1,128 @@
+"""Python face of the host-side callers (include/rt_host.h): Scene.LoadScene, camera uniforms, Renderer frame
+conversion, BVH build.  Thin ctypes calls into librt_core.so — the work is done by the C++ classes in
+raytracing_amd/csrc/host/ that mirror the reference's Scene / Model / Light / Camera / Renderer."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .core import RtError
+
+HOST_EXPORTS = ["rth_last_error", "rth_load_scene", "rth_load_models", "rth_scene_buffer", "rth_load_timings",
+                "rth_build_bvh", "rth_free", "rth_set_camera", "rth_orbit_camera", "rth_frame_rgba8", "rth_decode_png"]
+
+_bound = False
+
+
+def _L():
+    global _bound
+    lib = _lib.load()
+    if not _bound:
+        vp, u32, u64, i32, f = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
+        lib.rth_last_error.restype = C.c_char_p
+        lib.rth_last_error.argtypes = []
+        lib.rth_load_scene.restype = i32
+        lib.rth_load_scene.argtypes = [vp, C.c_char_p, i32]
+        lib.rth_load_models.restype = i32
+        lib.rth_load_models.argtypes = [vp, C.POINTER(C.c_char_p), i32, C.POINTER(f), i32]
+        lib.rth_scene_buffer.restype = i32
+        lib.rth_scene_buffer.argtypes = [u32, C.POINTER(vp), C.POINTER(u64)]
+        lib.rth_load_timings.restype = i32
+        lib.rth_load_timings.argtypes = [C.POINTER(C.c_double)]
+        lib.rth_build_bvh.restype = i32
+        lib.rth_build_bvh.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(u64)]
+        lib.rth_free.restype = None
+        lib.rth_free.argtypes = [vp]
+        lib.rth_set_camera.restype = i32
+        lib.rth_set_camera.argtypes = [vp, C.POINTER(f), C.POINTER(f), f, f, f]
+        lib.rth_orbit_camera.restype = None
+        lib.rth_orbit_camera.argtypes = [i32, C.POINTER(f), C.POINTER(f)]
+        lib.rth_frame_rgba8.restype = i32
+        lib.rth_frame_rgba8.argtypes = [vp, u32, u32, vp]
+        lib.rth_decode_png.restype = i32
+        lib.rth_decode_png.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
+        _bound = True
+    return lib
+
+
+def _chk(st):
+    if st != 0:
+        raise RtError(st, (_L().rth_last_error() or b"").decode())
+
+
+def _h(cs):
+    return cs._h if cs is not None else None
+
+
+DEFAULT_CAMERA = ((0.0, 3.5, 14.0), (0.0, 0.0, -1.0))   # main.cpp:239, camera.h:21
+
+
+class Scene:
+    """Scene::LoadScene (Scene.cpp:15-62).  cs=None runs the loader without a GPU (buffers only)."""
+
+    @staticmethod
+    def LoadScene(cs, scene_index, models_root):
+        _chk(_L().rth_load_scene(_h(cs), str(models_root).encode(), int(scene_index)))
+
+    @staticmethod
+    def LoadModels(cs, gltf_paths, lights):
+        """lights: [(loc, dir, type, strength)] as in Scene.cpp's Light(...) calls."""
+        arr = (C.c_char_p * len(gltf_paths))(*[str(p).encode() for p in gltf_paths])
+        flat = []
+        for loc, d, typ, strength in lights:
+            flat += [float(v) for v in loc] + [float(v) for v in d] + [float(typ), float(strength)]
+        la = (C.c_float * max(1, len(flat)))(*flat)
+        _chk(_L().rth_load_models(_h(cs), arr, len(gltf_paths), la, len(lights)))
+
+    @staticmethod
+    def buffer(slot):
+        """Host copy (bytes) of what the last load bound to `slot`."""
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(_L().rth_scene_buffer(slot, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value) if n.value else b""
+
+    @staticmethod
+    def timings():
+        t = (C.c_double * 3)()
+        _chk(_L().rth_load_timings(t))
+        return {"flatten_s": t[0], "bvh_build_s": t[1], "upload_s": t[2]}
+
+
+def build_bvh(triangles):
+    """Model::buildBVH + convertToGPU on a [n] array of 128-byte Triangle records -> bytes of 48-byte nodes."""
+    buf = np.ascontiguousarray(triangles)
+    assert buf.dtype.itemsize == 128
+    out, n = C.c_void_p(), C.c_uint64()
+    _chk(_L().rth_build_bvh(buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(out), C.byref(n)))
+    raw = C.string_at(out.value, n.value * 48)
+    _L().rth_free(out)
+    return raw
+
+
+def set_camera(cs, position, orientation, width, height, fov=45.0):
+    """The per-frame uniforms of main.cpp:109-123."""
+    p = (C.c_float * 3)(*[float(v) for v in position])
+    o = (C.c_float * 3)(*[float(v) for v in orientation])
+    _chk(_L().rth_set_camera(cs._h, p, o, float(width), float(height), float(fov)))
+
+
+def orbit_camera(frame):
+    """Renderer::UpdateCamera (Renderer.cpp:187-193)."""
+    p, o = (C.c_float * 3)(), (C.c_float * 3)()
+    _L().rth_orbit_camera(int(frame), p, o)
+    return tuple(p), tuple(o)
+
+
+def frame_rgba8(cs):
+    """Renderer::NextFrame's 8-bit conversion (Renderer.cpp:95-124): [H, W, 4] uint8, top row first."""
+    out = np.empty((cs.height, cs.width, 4), np.uint8)
+    _chk(_L().rth_frame_rgba8(cs._h, cs.width, cs.height, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def decode_png(path):
+    p, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
+    _chk(_L().rth_decode_png(str(path).encode(), C.byref(p), C.byref(w), C.byref(h)))
+    a = np.frombuffer(C.string_at(p.value, w.value * h.value * 4), np.uint8).reshape(h.value, w.value, 4).copy()
+    _L().rth_free(p)
+    return a
