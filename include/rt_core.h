@@ -72,7 +72,8 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * invView, time ...) are accepted and ignored, as glGetUniformLocation == -1 is in GL.
  * Extension names (no reference counterpart): traversalMode (0 = culled/ordered, 1 = reference-order
  * exhaustive), timeKernels (1 = HIP-event timing per kernel class into rt_stats), countVisits (1 = run the
- * instrumented traversal kernels that count node visits / triangle tests). */
+ * instrumented traversal kernels that count node visits / triangle tests), samplesPerPass (samples of a pixel
+ * traced concurrently; results do not depend on it), blocksPerCU (persistent grid size). */
 rt_status rt_set_int(rt_ctx* ctx, const char* name, int32_t v);
 rt_status rt_set_float(rt_ctx* ctx, const char* name, float v);
 rt_status rt_set_vec2(rt_ctx* ctx, const char* name, const float v[2]);
@@ -117,6 +118,7 @@ typedef struct rt_stats {
     uint64_t tri_tests;        /* closest-hit kernel: 48-byte triangle records tested (countVisits = 1) */
     uint64_t shadow_node_visits; /* same two counters for the shadow kernel */
     uint64_t shadow_tri_tests;
+    uint64_t max_ray_steps;    /* most node visits + triangle tests by a single closest-hit ray (countVisits = 1) */
     double   ms_total;         /* wall time of the render call, host clock                     */
     double   ms_extend;        /* summed HIP-event time of the closest-hit kernels (timeKernels = 1) */
     double   ms_shade;         /* ... of the shading kernels                                   */

@@ -19,7 +19,7 @@ class RtConfig(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("rays_shadow_skipped", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
+                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64), ("max_ray_steps", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
                 ("launches_extend", C.c_uint64), ("launches_shade", C.c_uint64), ("launches_shadow", C.c_uint64)]
 

@@ -1,6 +1,7 @@
 // librt_core.so — C ABI of the MI355X path-tracing core (include/rt_core.h).
 // Host orchestration of the wavefront kernels in rt_kernels.hip.h.  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -40,7 +41,7 @@ struct rt_ctx {
     float camPos[3] = {0, 0, 0}, camForward[3] = {0, 0, -1}, camRight[3] = {1, 0, 0}, camUp[3] = {0, 1, 0};
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
-    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0;
+    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 16, blocksPerCU = 8;
 
     // device scene
     DevBuf dNodes, dTris, dShade, dMaterials, dVertices, dLights, dTexDescs;
@@ -55,7 +56,7 @@ struct rt_ctx {
     bool primValid = false;
 
     // path state
-    DevBuf rayO, rayD, rayS, hit, pend, accum, queues, shadowQueue, counters, dStats;
+    DevBuf rayO, rayD, rayS, hit, contrib, depth, accum, queues, shadowQueue, counters, dStats, overflow;
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
 
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; bool used = false; };
@@ -164,15 +165,31 @@ SceneView make_view(rt_ctx* c, bool exact) {
 
 bool use_exact(rt_ctx* c) { return c->traversalMode == 1 || !c->cs.boxesContainTris; }
 
-rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t nLights, uint32_t maxBounces) {
+// Launch geometry of the persistent traversal / shading kernels and the stack overflow area that goes with it.
+uint32_t trace_blocks(rt_ctx* c, uint32_t nslots) {
+    uint32_t slotBlocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
+    uint32_t persistent = (uint32_t)c->numCUs * (uint32_t)c->blocksPerCU;
+    return slotBlocks < persistent ? slotBlocks : persistent;
+}
+uint32_t overflow_depth(rt_ctx* c) {
+    // ordered traversal keeps at most one pending sibling per level: depth <= tree depth
+    int need = (int)c->cs.maxDepth + 1 - RT_LDS_STACK;
+    if (need < 0) need = 0;
+    if (need > RT_SPILL_STACK) need = RT_SPILL_STACK;
+    return (uint32_t)need;
+}
+
+rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
     rt_status s;
     size_t n = nslots;
+    if ((s = ensure(c, c->overflow, (size_t)overflow_depth(c) * trace_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
     if ((s = ensure(c, c->rayO, n * 16))) return s;
     if ((s = ensure(c, c->rayD, n * 16))) return s;
     if ((s = ensure(c, c->rayS, n * 16))) return s;
     if ((s = ensure(c, c->hit, n * 16))) return s;
-    if ((s = ensure(c, c->pend, n * 16 * (nLights ? nLights : 1)))) return s;
-    if ((s = ensure(c, c->accum, n * 16))) return s;
+    if ((s = ensure(c, c->contrib, n * 16 * lightSlots * std::max<uint32_t>(1, maxBounces)))) return s;
+    if ((s = ensure(c, c->depth, n * 4))) return s;
+    if ((s = ensure(c, c->accum, (size_t)slotsPerSample * 16))) return s;
     if ((s = ensure(c, c->queues, n * 4 * 2))) return s;
     if ((s = ensure(c, c->shadowQueue, n * 4))) return s;
     if ((s = ensure(c, c->counters, (size_t)(2 * (maxBounces + 1)) * 4))) return s;
@@ -180,11 +197,13 @@ rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t nLights, uint32_t ma
     return RT_OK;
 }
 
-PathBuffers make_paths(rt_ctx* c, uint32_t nslots) {
+PathBuffers make_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots) {
     PathBuffers P;
     P.rayO = (float4*)c->rayO.p; P.rayD = (float4*)c->rayD.p; P.rayS = (float4*)c->rayS.p; P.hit = (float4*)c->hit.p;
-    P.pend = (float4*)c->pend.p; P.accum = (float4*)c->accum.p; P.queues = (uint32_t*)c->queues.p;
-    P.shadowQueue = (uint32_t*)c->shadowQueue.p; P.counters = (uint32_t*)c->counters.p; P.nslots = nslots;
+    P.contrib = (float4*)c->contrib.p; P.depth = (uint32_t*)c->depth.p; P.accum = (float4*)c->accum.p;
+    P.queues = (uint32_t*)c->queues.p; P.shadowQueue = (uint32_t*)c->shadowQueue.p; P.counters = (uint32_t*)c->counters.p;
+    P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots;
+    P.overflow = (uint2*)c->overflow.p; P.overflowStride = trace_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
 }
 
@@ -216,8 +235,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     F.width = (int)c->width; F.height = (int)c->height;
     F.rx = (int)x; F.ry = (int)y; F.rw = (int)w; F.rh = (int)h;
     F.tilesX = (int)((w + 7) / 8);
-    uint32_t tilesY = (h + 7) / 8;
-    uint32_t nslots = (uint32_t)F.tilesX * tilesY * 64u;
+    const uint32_t tilesY = (h + 7) / 8;
+    const uint32_t sps = (uint32_t)F.tilesX * tilesY * 64u;            // slots per sample
     F.numLights = c->numLights < 0 ? 0 : c->numLights; F.hasSun = c->hasSun;
     for (int k = 0; k < 3; k++) { F.camPos[k] = c->camPos[k]; F.camForward[k] = c->camForward[k]; F.camRight[k] = c->camRight[k]; F.camUp[k] = c->camUp[k]; }
     F.aspect = c->aspect;
@@ -227,9 +246,18 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     F.initialStrength = 1.f / (float)c->samplesPerPixel;               // shader.comp:307
     F.strengthCutoff = .01f / (float)c->samplesPerPixel;               // shader.comp:306
 
+    // Samples in flight per pass: enough rays per launch to amortise the latency-bound tail of the traversal
+    // kernels, bounded by a slot budget.
     const uint32_t maxB = (uint32_t)c->maxBounces;
-    if ((s = ensure_paths(c, nslots, (uint32_t)F.numLights, maxB))) return s;
-    PathBuffers P = make_paths(c, nslots);
+    uint32_t S_ = (uint32_t)(c->samplesPerPass < 1 ? 1 : c->samplesPerPass);
+    const uint64_t slotBudget = 1ull << 25;
+    if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
+    if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
+    const uint32_t nslots = S_ * sps;
+    const uint32_t lightSlots = (uint32_t)std::max(1, F.numLights);
+
+    if ((s = ensure_paths(c, nslots, sps, lightSlots, maxB))) return s;
+    PathBuffers P = make_paths(c, nslots, sps, lightSlots);
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;
     SceneView S = make_view(c, exact);
@@ -250,11 +278,10 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         HIPCHK(c, hipMemsetAsync(c->primTri.p, 0xFF, (size_t)c->width * c->height * 4, st));
         HIPCHK(c, hipMemsetAsync(c->primHit.p, 0, (size_t)c->width * c->height * 12, st));
     }
-    const uint32_t slotBlocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
-    k_init_frame<<<slotBlocks, RT_BLOCK, 0, st>>>(F, P, iAlb, iNor, iDep);
+    const uint32_t pixBlocks = (sps + RT_BLOCK - 1) / RT_BLOCK;
+    k_init_frame<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, iAlb, iNor, iDep);
 
-    const uint32_t persistent = (uint32_t)c->numCUs * 8u;
-    const uint32_t traceBlocks = slotBlocks < persistent ? slotBlocks : persistent;
+    const uint32_t traceBlocks = trace_blocks(c, nslots);
     uint32_t* qcount = P.counters;
     uint32_t* scount = P.counters + (maxB + 1);
     // Optional per-kernel-class timing with HIP events on the launch stream (ring of pairs, drained lazily).
@@ -284,28 +311,34 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     };
     auto evEnd = [&](rt_ctx::EvPair* e) { if (e) (void)hipEventRecord(e->b, st); };
 
-    for (uint32_t r = r0; r < r1; r++) {
+    for (uint32_t rBase = r0; rBase < r1; rBase += S_) {
+        const uint32_t inPass = std::min(S_, r1 - rBase);
+        PathBuffers Pp = P;
+        Pp.nslots = inPass * sps;                  // a short last pass uses its own (smaller) log strides
+        const uint32_t passBlocks = (Pp.nslots + RT_BLOCK - 1) / RT_BLOCK;
+        const uint32_t tb = std::min(traceBlocks, passBlocks);
         HIPCHK(c, hipMemsetAsync(P.counters, 0, (size_t)(2 * (maxB + 1)) * 4, st));
-        k_raygen<<<slotBlocks, RT_BLOCK, 0, st>>>(F, P, (int)r, P.queues, qcount);
+        k_raygen<<<passBlocks, RT_BLOCK, 0, st>>>(F, Pp, (int)rBase, qcount);
         for (uint32_t b = 0; b < maxB; b++) {
-            uint32_t* qin = P.queues + (size_t)(b & 1) * nslots;
+            uint32_t* qin = b == 0 ? nullptr : P.queues + (size_t)(b & 1) * nslots;   // bounce 0: identity queue
             uint32_t* qout = P.queues + (size_t)((b + 1) & 1) * nslots;
             rt_ctx::EvPair* e = evBegin(0);
-            launch_extend(exact, count, dim3(traceBlocks), st, S, P, (const uint32_t*)qin, (const uint32_t*)(qcount + b), b == 0 ? 1 : 0, dst);
+            launch_extend(exact, count, dim3(tb), st, S, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), b == 0 ? 1 : 0,
+                          b == 0 ? inPass * w * h : 0u, dst);
             evEnd(e);
             e = evBegin(1);
-            k_shade<<<traceBlocks, RT_BLOCK, 0, st>>>(S, F, P, (const uint32_t*)qin, (const uint32_t*)(qcount + b), qout, qcount + b + 1,
-                                                       scount + b, (int)r, (int)b, r == 0 ? iAlb : nullptr, r == 0 ? iNor : nullptr,
-                                                       r == 0 ? iDep : nullptr, r == 0 ? pTri : nullptr, r == 0 ? pHit : nullptr, dst);
+            k_shade<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), qout, qcount + b + 1,
+                                              scount + b, (int)rBase, (int)b, iAlb, iNor, iDep, pTri, pHit, dst);
             evEnd(e);
             if (F.numLights > 0) {
                 e = evBegin(2);
-                launch_shadow(exact, count, dim3(traceBlocks), st, S, F, P, (const uint32_t*)(scount + b), dst);
+                launch_shadow(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
                 evEnd(e);
             }
         }
+        k_resolve<<<pixBlocks, RT_BLOCK, 0, st>>>(Pp, (int)inPass, (int)maxB);
     }
-    k_finalize<<<slotBlocks, RT_BLOCK, 0, st>>>(F, P, (float4*)c->img[0].p);
+    k_finalize<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, (float4*)c->img[0].p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
     if (timeKernels) for (auto& e : c->evRing) evDrain(e);
@@ -318,6 +351,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.rays_shadow_skipped = hs.rays_shadow_skipped; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
     c->stats.ms_total = std::chrono::duration<double, std::milli>(t1 - t0).count();
     c->stats.shadow_node_visits = hs.shadow_node_visits; c->stats.shadow_tri_tests = hs.shadow_tri_tests;
+    c->stats.max_ray_steps = hs.max_ray_steps;
     c->stats.ms_extend = msAcc[0]; c->stats.ms_shade = msAcc[1]; c->stats.ms_shadow = msAcc[2];
     c->stats.launches_extend = nLaunch[0]; c->stats.launches_shade = nLaunch[1]; c->stats.launches_shadow = nLaunch[2];
     c->primValid = aov;
@@ -354,7 +388,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->dNodes, &c->dTris, &c->dShade, &c->dMaterials, &c->dVertices, &c->dLights, &c->dTexDescs,
                       &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->rayO, &c->rayD, &c->rayS,
-                      &c->hit, &c->pend, &c->accum, &c->queues, &c->shadowQueue, &c->counters, &c->dStats};
+                      &c->hit, &c->contrib, &c->depth, &c->accum, &c->queues, &c->shadowQueue, &c->counters, &c->dStats, &c->overflow};
     for (DevBuf* b : bufs) b->release();
     for (auto& t : c->textures) t.data.release();
     for (auto& e : c->evRing) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
@@ -386,6 +420,8 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "traversalMode")) c->traversalMode = v;
     else if (name_is(name, "timeKernels")) c->timeKernels = v;
     else if (name_is(name, "countVisits")) c->countVisits = v;
+    else if (name_is(name, "samplesPerPass")) c->samplesPerPass = v;
+    else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
 }
 rt_status rt_set_float(rt_ctx* c, const char* name, float v) {
@@ -503,8 +539,8 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     if (!hadLights) c->slotSet[RT_SLOT_LIGHTS] = false;
     if (s) return s;
     uint32_t nslots = (uint32_t)((n + 63) / 64 * 64);
-    if ((s = ensure_paths(c, nslots, 1, 1))) return s;
-    PathBuffers P = make_paths(c, nslots);
+    if ((s = ensure_paths(c, nslots, nslots, 1, 1))) return s;
+    PathBuffers P = make_paths(c, nslots, nslots, 1);
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;
     SceneView S = make_view(c, exact);
@@ -516,9 +552,8 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     (void)hipMemsetAsync(dst, 0, sizeof(DeviceStats), st);
     uint32_t blocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
     k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, (const float*)dO.p, (const float*)dD.p, (uint32_t)n, P.queues, P.counters);
-    uint32_t persistent = (uint32_t)c->numCUs * 8u;
-    launch_extend(exact, count, dim3(blocks < persistent ? blocks : persistent), st, S, P, (const uint32_t*)P.queues,
-                  (const uint32_t*)P.counters, 1, dst);
+    launch_extend(exact, count, dim3(trace_blocks(c, nslots)), st, S, P, (const uint32_t*)P.queues,
+                  (const uint32_t*)P.counters, 1, 0u, dst);
     hipError_t e = hipStreamSynchronize(st);
     std::vector<float> h4(n * 4);
     if (e == hipSuccess) e = hipMemcpy(h4.data(), P.hit, n * 16, hipMemcpyDeviceToHost);

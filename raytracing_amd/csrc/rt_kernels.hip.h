@@ -1,12 +1,14 @@
 // gfx950 wavefront path-tracing kernels (included by rt_core.hip).
 //
-// Pipeline per sample r (one path per pixel in flight; DESIGN.md "Wavefront pipeline"):
-//   k_raygen            shader.comp:309-324   ray generation, queue 0
+// Pipeline per pass of S samples (S paths per pixel in flight; DESIGN.md "Wavefront pipeline"):
+//   k_raygen            shader.comp:309-324   ray generation for samples [rBase, rBase+S)
 //   for bounce b:
 //     k_extend          shader.comp:243-290   closest hit (lineCast) over queue b
 //     k_shade           shader.comp:329-452,524-531  miss/ambient, surface fetch, dielectric/GGX bounce,
-//                                              light evaluation -> pending contribution, queue b+1
-//     k_shadow          shader.comp:453-522   shadow lineCast per pending light, accumulate
+//                                              light evaluation -> contribution log, queue b+1
+//     k_shadow          shader.comp:453-484   shadow lineCast per pending light -> confirms / cancels the log entry
+//   k_resolve           shader.comp:332,521   replays the log into the pixel colour in the reference's order
+//                                              (sample, bounce, light), so float sums are bit-identical to the serial shader
 //   k_finalize          shader.comp:533-536   image stores
 // Compaction between stages: wave64 ballot + mbcnt prefix, one atomic per wave.
 #pragma once
@@ -24,27 +26,59 @@ struct PathBuffers {
     float4* rayD;        // d.xyz
     float4* rayS;        // strength.xyz
     float4* hit;         // hitLoc.xyz, w = reference triangle index bits (-1 miss)
-    float4* pend;        // [numLights][nslots] rgb of a light's contribution, w = 1 when a shadow ray is due
-    float4* accum;       // [nslots] running pixel colour (the shader's `color`)
+    float4* contrib;     // contribution log [maxBounces][lightSlots][nslots]: rgb, w = 0 none / 1 awaiting shadow ray / 2 add
+    uint32_t* depth;     // [nslots] bounces shaded so far by the slot's path (log entries [0, depth) are valid)
+    float4* accum;       // [slotsPerSample] running pixel colour (the shader's `color`), survives passes
     uint32_t* queues;    // [2][nslots]
     uint32_t* shadowQueue;
     uint32_t* counters;  // [0..maxB] path-queue sizes per bounce, [maxB+1 .. 2maxB+1] shadow-queue sizes
-    uint32_t nslots;
+    uint2* overflow;     // traversal-stack entries beyond the LDS part: entry k of thread g at overflow[k*overflowStride + g]
+    uint32_t overflowStride, overflowDepth;
+    uint32_t nslots;     // slots in flight = samples per pass x slotsPerSample
+    uint32_t slotsPerSample, lightSlots;   // lightSlots = max(1, numLights)
 };
 
 // ---------------------------------------------------------------------------------------------
-// wave64 append: returns this lane's output index (valid lanes only); one atomic per wave.
-__device__ __forceinline__ uint32_t wave_append(bool valid, uint32_t* counter) {
-    unsigned long long mask = __ballot(valid);
-    uint32_t n = (uint32_t)__popcll(mask);
-    uint32_t lanePrefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    uint32_t base = 0;
-    if (n) {
-        int leader = __ffsll((long long)mask) - 1;
-        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, n);
-        base = (uint32_t)__shfl((int)base, leader, 64);
+// Block-aggregated stream compaction for RT_ITEMS flags per thread and NQ output queues:
+// wave64 ballot + mbcnt prefix inside each wave, wave totals combined through LDS, ONE atomic per queue per
+// block (a single counter word sustains only ~88 atomics/us on MI355X, so per-wave atomics would bound the
+// kernel).  Returns the output index of item k of this thread in idx[q][k] (valid where flag set).
+#define RT_ITEMS 4
+template <int NQ>
+__device__ __forceinline__ void block_append(const bool (&flag)[NQ][RT_ITEMS], uint32_t* const (&counter)[NQ],
+                                             uint32_t (&idx)[NQ][RT_ITEMS], uint32_t* ldsScratch /* >= NQ*8 words */) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t waveTotal[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) {
+            unsigned long long m = __ballot(flag[q][k]);
+            uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            idx[q][k] = run + pre;
+            run += (uint32_t)__popcll(m);
+        }
+        waveTotal[q] = run;
+        if (lane == 0) ldsScratch[q * 8 + wave] = run;
     }
-    return base + lanePrefix;
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        const int q = threadIdx.x;
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < RT_BLOCK / 64; w++) { uint32_t c = ldsScratch[q * 8 + w]; ldsScratch[q * 8 + w] = t; t += c; }
+        uint32_t base = t ? atomicAdd(counter[q], t) : 0u;
+        ldsScratch[q * 8 + 4] = base;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        uint32_t off = ldsScratch[q * 8 + 4] + ldsScratch[q * 8 + wave];
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) idx[q][k] += off;
+    }
+    __syncthreads();   // ldsScratch is reused by the next chunk
+    (void)waveTotal;
 }
 
 __device__ __forceinline__ void slot_to_pixel(const FrameParams& F, uint32_t slot, int* px, int* py) {
@@ -99,10 +133,30 @@ __device__ __forceinline__ void test_tri(const CTri* __restrict__ tris, int idx,
     }
 }
 
-struct StackRef {
-    uint2* lds;          // this lane's column in LDS: entry k at lds[k * RT_BLOCK]
-    uint2 spill[RT_SPILL_STACK];
+// Per-lane traversal stack: the first RT_LDS_STACK entries live in LDS (entry k of thread t at lds[k*RT_BLOCK + t]:
+// consecutive lanes hit consecutive 8-byte slots, conflict-free), deeper entries in a global overflow area sized
+// from the tree depth at scene load (coalesced the same way).  No scratch memory is used.  A push beyond the
+// total capacity (>= 64 entries = shader.comp:246) is dropped like the reference's `stackPtr < 64` guard.
+struct Stack {
+    uint2* lds; uint2* ov; uint32_t ovStride; int cap;
+    __device__ __forceinline__ void push(int& sp, uint2 e) const {
+        if (sp < RT_LDS_STACK) lds[sp * RT_BLOCK] = e;
+        else if (sp < cap) ov[(size_t)(sp - RT_LDS_STACK) * ovStride] = e;
+        if (sp < cap) sp++;
+    }
+    __device__ __forceinline__ uint2 pop(int& sp) const {
+        sp--;
+        return (sp < RT_LDS_STACK) ? lds[sp * RT_BLOCK] : ov[(size_t)(sp - RT_LDS_STACK) * ovStride];
+    }
 };
+__device__ __forceinline__ Stack make_stack(uint2* ldsBase, const struct PathBuffers& P) {
+    Stack st;
+    st.lds = ldsBase + threadIdx.x;
+    st.ov = P.overflow + (blockIdx.x * RT_BLOCK + threadIdx.x);
+    st.ovStride = P.overflowStride;
+    st.cap = RT_LDS_STACK + (int)P.overflowDepth;
+    return st;
+}
 
 // Closest hit == lineCast (shader.comp:243-290).
 //   EXACT:  reference order (right child first), no culling, leaf children always entered.
@@ -110,7 +164,7 @@ struct StackRef {
 //   ANYHIT: stop at the first accepted hit with t-independent predicate `accept` (sun: any hit;
 //           point light: distance(hit, shadeLoc) < distToLight), see k_shadow.
 template <bool EXACT, bool COUNT>
-__device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, uint2* ldsCol, HitRec& best,
+__device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, const Stack& stk, HitRec& best,
                                             uint32_t& nNodes, uint32_t& nTris) {
     best.dist = 3.40282347e+38f; best.t = __int_as_float(0x7f800000); best.idx = -1; best.ref = -1;
     best.loc = mk(0.f, 0.f, 0.f);
@@ -118,7 +172,6 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, uint
     float te;
     if (COUNT) nNodes++;
     if (!slab(o, inv, S.rootLo, S.rootHi, &te)) return false;
-    uint2 spill[RT_SPILL_STACK];
     int sp = 0;
     int cur = S.rootChild;
     while (true) {
@@ -139,8 +192,7 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, uint
                 // reference pops children.y first (shader.comp:281-284)
                 if (p0 && p1) {
                     uint2 e; e.x = (uint32_t)c0; e.y = 0u;
-                    if (sp < RT_LDS_STACK) ldsCol[sp * RT_BLOCK] = e; else if (sp < RT_LDS_STACK + RT_SPILL_STACK) spill[sp - RT_LDS_STACK] = e;
-                    if (sp < RT_LDS_STACK + RT_SPILL_STACK) sp++;
+                    stk.push(sp, e);
                     cur = c1; continue;
                 }
                 if (p1) { cur = c1; continue; }
@@ -154,8 +206,7 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, uint
                     int nearC = swap ? c1 : c0, farC = swap ? c0 : c1;
                     float farT = swap ? t0 : t1;
                     uint2 e; e.x = (uint32_t)farC; e.y = __float_as_uint(farT);
-                    if (sp < RT_LDS_STACK) ldsCol[sp * RT_BLOCK] = e; else if (sp < RT_LDS_STACK + RT_SPILL_STACK) spill[sp - RT_LDS_STACK] = e;
-                    if (sp < RT_LDS_STACK + RT_SPILL_STACK) sp++;
+                    stk.push(sp, e);
                     cur = nearC; continue;
                 }
                 if (p0) { cur = c0; continue; }
@@ -172,8 +223,7 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, uint
         // pop
         bool got = false;
         while (sp > 0) {
-            sp--;
-            uint2 e = (sp < RT_LDS_STACK) ? ldsCol[sp * RT_BLOCK] : spill[sp - RT_LDS_STACK];
+            uint2 e = stk.pop(sp);
             if (!EXACT) {
                 float lim = best.t + best.t * 1e-4f + S.cullAbs;
                 if (__uint_as_float(e.y) > lim) continue;
@@ -191,14 +241,13 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, uint
 // boxes entered beyond distToLight (+slack) are skipped; traversalMode 1 runs the full closest-hit.
 template <bool COUNT>
 __device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, int kind, v3 shadeLoc, float distToLight,
-                                              uint2* ldsCol, uint32_t& nNodes, uint32_t& nTris) {
+                                              const Stack& stk, uint32_t& nNodes, uint32_t& nTris) {
     v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float te;
     if (COUNT) nNodes++;
     if (!slab(o, inv, S.rootLo, S.rootHi, &te)) return false;
     // For point lights |d| = 1 so t ~ distance from o; o is within ~1e-5*|n| of shadeLoc.
     float lim = (kind == 0) ? (distToLight + distToLight * 1e-3f + S.cullAbs * 4.0f) : __int_as_float(0x7f800000);
-    uint2 spill[RT_SPILL_STACK];
     int sp = 0;
     int cur = S.rootChild;
     while (true) {
@@ -214,8 +263,7 @@ __device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, in
             bool p1 = slab(o, inv, lo1, hi1, &t1) && !(t1 > lim);
             if (p0 && p1) {
                 uint2 e; e.x = (uint32_t)c1; e.y = 0u;
-                if (sp < RT_LDS_STACK) ldsCol[sp * RT_BLOCK] = e; else if (sp < RT_LDS_STACK + RT_SPILL_STACK) spill[sp - RT_LDS_STACK] = e;
-                if (sp < RT_LDS_STACK + RT_SPILL_STACK) sp++;
+                stk.push(sp, e);
                 cur = c0; continue;
             }
             if (p0) { cur = c0; continue; }
@@ -235,62 +283,74 @@ __device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, in
             }
         }
         if (sp == 0) break;
-        sp--;
-        uint2 e = (sp < RT_LDS_STACK) ? ldsCol[sp * RT_BLOCK] : spill[sp - RT_LDS_STACK];
+        uint2 e = stk.pop(sp);
         cur = (int)e.x;
     }
     return false;
 }
 
 // ---------------------------------------------------------------------------------------------
-// shader.comp:309-324 for sample r, one thread per slot of the region's 8x8-tiled slot space.
-__global__ __launch_bounds__(RT_BLOCK) void k_raygen(FrameParams F, PathBuffers P, int r, uint32_t* queueOut, uint32_t* countOut) {
+// shader.comp:309-324 for sample r, one thread per slot of the region's 8x8-tiled slot space.  Bounce 0 needs no
+// queue: every slot carries a path (slots of edge tiles that fall outside the region are flagged dead).
+#define RT_FLAG_REFRACTING 1u
+#define RT_FLAG_DEAD 2u
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(FrameParams F, PathBuffers P, int rBase, uint32_t* countOut) {
     uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
-    bool valid = false;
-    if (slot < P.nslots) {
-        int px, py;
-        slot_to_pixel(F, slot, &px, &py);
-        valid = px < F.rx + F.rw && py < F.ry + F.rh;
-        if (valid) {
-            int N = F.gridN;
-            int gx = r % N, gy = r / N;
-            float jx = ((float)gx + 0.5f) / (float)N, jy = ((float)gy + 0.5f) / (float)N;
-            float ux = ((float)px + jx) / (float)F.width * 2.0f - 1.0f;
-            float uy = ((float)py + jy) / (float)F.height * 2.0f - 1.0f;
-            ux *= F.aspect;
-            float fx = ux * F.tanHalfFov;
-            float fy = uy * F.tanHalfFov;
-            v3 fwd = ld3(F.camForward), right = ld3(F.camRight), up = ld3(F.camUp);
-            v3 dir = (fwd + fx * right + fy * up);
-            P.rayO[slot] = make_float4(F.camPos[0], F.camPos[1], F.camPos[2], __uint_as_float(0u));
-            P.rayD[slot] = make_float4(dir.x, dir.y, dir.z, 0.f);
-            P.rayS[slot] = make_float4(F.initialStrength, F.initialStrength, F.initialStrength, 0.f);
-        }
-    }
-    uint32_t idx = wave_append(valid, countOut);
-    if (valid) queueOut[idx] = slot;
+    if (slot == 0) *countOut = P.nslots;
+    if (slot >= P.nslots) return;
+    int px, py;
+    int r = rBase + (int)(slot / P.slotsPerSample);
+    slot_to_pixel(F, slot % P.slotsPerSample, &px, &py);
+    P.depth[slot] = 0u;
+    bool valid = px < F.rx + F.rw && py < F.ry + F.rh;
+    int N = F.gridN;
+    int gx = r % N, gy = r / N;
+    float jx = ((float)gx + 0.5f) / (float)N, jy = ((float)gy + 0.5f) / (float)N;
+    float ux = ((float)px + jx) / (float)F.width * 2.0f - 1.0f;
+    float uy = ((float)py + jy) / (float)F.height * 2.0f - 1.0f;
+    ux *= F.aspect;
+    float fx = ux * F.tanHalfFov;
+    float fy = uy * F.tanHalfFov;
+    v3 fwd = ld3(F.camForward), right = ld3(F.camRight), up = ld3(F.camUp);
+    v3 dir = (fwd + fx * right + fy * up);
+    P.rayO[slot] = make_float4(F.camPos[0], F.camPos[1], F.camPos[2], __uint_as_float(valid ? 0u : RT_FLAG_DEAD));
+    P.rayD[slot] = make_float4(dir.x, dir.y, dir.z, 0.f);
+    P.rayS[slot] = make_float4(F.initialStrength, F.initialStrength, F.initialStrength, 0.f);
 }
 
+// queue == nullptr: identity (bounce 0).  rayCount > 0 overrides the number of rays added to the counters
+// (bounce 0: region pixels, not slots).
 template <bool EXACT, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, PathBuffers P, const uint32_t* __restrict__ queue,
-                                                     const uint32_t* __restrict__ count, int isPrimary, DeviceStats* stats) {
+                                                     const uint32_t* __restrict__ count, int isPrimary, uint32_t rayCount,
+                                                     DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    const Stack stk = make_stack(lds, P);
     uint32_t n = *count;
-    uint32_t nNodes = 0, nTris = 0;
+    uint32_t nNodes = 0, nTris = 0, maxSteps = 0;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
-        uint32_t slot = queue[i];
+        uint32_t slot = queue ? queue[i] : i;
         float4 o4 = P.rayO[slot], d4 = P.rayD[slot];
+        if (__float_as_uint(o4.w) & RT_FLAG_DEAD) { P.hit[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-2)); continue; }
         HitRec best;
-        closest_hit<EXACT, COUNT>(S, mk(o4.x, o4.y, o4.z), mk(d4.x, d4.y, d4.z), lds + threadIdx.x, best, nNodes, nTris);
+        uint32_t before = nNodes + nTris;
+        closest_hit<EXACT, COUNT>(S, mk(o4.x, o4.y, o4.z), mk(d4.x, d4.y, d4.z), stk, best, nNodes, nTris);
+        if (COUNT) { uint32_t steps = nNodes + nTris - before; if (steps > maxSteps) maxSteps = steps; }
         P.hit[slot] = make_float4(best.loc.x, best.loc.y, best.loc.z, __int_as_float(best.ref));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        atomicAdd(isPrimary ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)n);
+        atomicAdd(isPrimary ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)(rayCount ? rayCount : n));
     if (COUNT) {
+        __shared__ uint32_t red[2];
+        if (threadIdx.x < 2) red[threadIdx.x] = 0;
+        __syncthreads();
         for (int off = 32; off > 0; off >>= 1) { nNodes += __shfl_down(nNodes, off, 64); nTris += __shfl_down(nTris, off, 64); }
-        if ((threadIdx.x & 63) == 0 && (nNodes | nTris)) {
-            atomicAdd(&stats->node_visits, (unsigned long long)nNodes);
-            atomicAdd(&stats->tri_tests, (unsigned long long)nTris);
+        for (int off = 32; off > 0; off >>= 1) { uint32_t o2 = __shfl_down(maxSteps, off, 64); if (o2 > maxSteps) maxSteps = o2; }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nNodes); atomicAdd(&red[1], nTris); if (maxSteps) atomicMax(&stats->max_ray_steps, (unsigned long long)maxSteps); }
+        __syncthreads();
+        if (threadIdx.x == 0 && (red[0] | red[1])) {
+            atomicAdd(&stats->node_visits, (unsigned long long)red[0]);
+            atomicAdd(&stats->tri_tests, (unsigned long long)red[1]);
         }
     }
 }
@@ -347,32 +407,44 @@ __device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float a
 // result parked in `pend` until k_shadow has traced the shadow ray (453-484).
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ count, uint32_t* queueOut, uint32_t* countOut,
-                                                    uint32_t* shadowCountOut, int r, int bounce,
+                                                    uint32_t* shadowCountOut, int rBase, int bounce,
                                                     float4* imgAlbedo, float4* imgNormal, float4* imgDepth,
                                                     int32_t* primTri, float* primHit, DeviceStats* stats) {
+    __shared__ uint32_t ldsAppend[16];
+    __shared__ uint32_t ldsCount[2];
+    if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
     uint32_t n = *count;
-    uint32_t nIter = (n + RT_BLOCK * gridDim.x - 1) / (RT_BLOCK * gridDim.x);
-    uint32_t skipped = 0;
-    for (uint32_t it = 0; it < nIter; it++) {
-        uint32_t i = (it * gridDim.x + blockIdx.x) * RT_BLOCK + threadIdx.x;
+    const uint32_t chunk = RT_BLOCK * RT_ITEMS;
+    uint32_t nChunks = (n + chunk - 1) / chunk;
+    uint32_t skipped = 0, pending = 0;
+    for (uint32_t ch = blockIdx.x; ch < nChunks; ch += gridDim.x) {
+      uint32_t contMask = 0, shadowMask = 0;
+#pragma unroll 1
+      for (int item = 0; item < RT_ITEMS; item++) {
+        uint32_t i = ch * chunk + (uint32_t)item * RT_BLOCK + threadIdx.x;
         bool live = i < n;
         bool cont = false, wantShadow = false;
         uint32_t slot = 0;
         if (live) {
-            slot = queue[i];
+            slot = queue ? queue[i] : i;
             float4 o4 = P.rayO[slot], d4 = P.rayD[slot], s4 = P.rayS[slot], h4 = P.hit[slot];
             v3 rayLoc = mk(o4.x, o4.y, o4.z), rayDir = mk(d4.x, d4.y, d4.z), strength = mk(s4.x, s4.y, s4.z);
-            bool refracting = (__float_as_uint(o4.w) & 1u) != 0u;
+            bool refracting = (__float_as_uint(o4.w) & RT_FLAG_REFRACTING) != 0u;
             int ref = __float_as_int(h4.w);
             int px, py;
-            slot_to_pixel(F, slot, &px, &py);
+            const int r = rBase + (int)(slot / P.slotsPerSample);
+            slot_to_pixel(F, slot % P.slotsPerSample, &px, &py);
             v3 camPos = ld3(F.camPos);
-            if (ref < 0) {
+            float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;   // entry of light l at logp[l * nslots]
+            if (ref != -2) P.depth[slot] = (uint32_t)bounce + 1u;
+            if (ref == -2) {
+                // dead slot (edge tile outside the region)
+            } else if (ref < 0) {
                 // miss: shader.comp:331-336
                 v3 ambient = F.hasSun ? mk(0.4431372549f, 0.73725490196f, 1.f) : mk(0.f, 0.f, 0.f);
-                float4 c = P.accum[slot];
-                v3 cc = mk(c.x, c.y, c.z) + ambient * strength;
-                P.accum[slot] = make_float4(cc.x, cc.y, cc.z, 1.f);
+                v3 cc = ambient * strength;
+                logp[0] = make_float4(cc.x, cc.y, cc.z, 2.f);
+                for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * P.nslots] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r == 0 && bounce == 0 && primTri) primTri[(size_t)py * F.width + px] = -1;
             } else {
                 v3 hitLoc = mk(h4.x, h4.y, h4.z);
@@ -486,6 +558,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 }
 
                 // light loop, shader.comp:453-522 minus the shadow lineCast (k_shadow)
+                if (F.numLights == 0) logp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int l = 0; l < F.numLights; l++) {
                     const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
                     float4 L0 = lp[0], L1 = lp[1], L2 = lp[2];
@@ -523,15 +596,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                         v3 radiance = mk(L2.x, L2.y, L2.z) * attenuation;
                         v3 contrib = (diffuse + specular) * radiance * NdotL * strength;
                         pendOut = make_float4(contrib.x, contrib.y, contrib.z, cast ? 1.f : 2.f);
-                        if (cast) wantShadow = true;
-                        else {
-                            // light type the shader does not know: no shadow test, contribution added directly
-                            float4 cA = P.accum[slot];
-                            P.accum[slot] = make_float4(cA.x + contrib.x, cA.y + contrib.y, cA.z + contrib.z, 1.f);
-                            pendOut.w = 0.f;
-                        }
+                        if (cast) { wantShadow = true; pending++; }
+                        // cast == false: a light type the shader does not know gets no shadow test and its
+                        // contribution (only reachable with a NaN normal) is added directly: w = 2
                     } else if (cast) skipped++;
-                    P.pend[(size_t)l * P.nslots + slot] = pendOut;
+                    logp[(size_t)l * P.nslots] = pendOut;
                 }
 
                 // shader.comp:524-530
@@ -540,7 +609,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 bool active = !(length3(strength) < F.strengthCutoff);
                 cont = active && (bounce + 1 < F.maxBounces);
                 if (cont || wantShadow) {
-                    P.rayO[slot] = make_float4(rayLoc.x, rayLoc.y, rayLoc.z, __uint_as_float(refracting ? 1u : 0u));
+                    P.rayO[slot] = make_float4(rayLoc.x, rayLoc.y, rayLoc.z, __uint_as_float(refracting ? RT_FLAG_REFRACTING : 0u));
                 }
                 if (cont) {
                     P.rayD[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.f);
@@ -548,31 +617,53 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 }
             }
         }
-        uint32_t qi = wave_append(cont, countOut);
-        if (cont) queueOut[qi] = slot;
-        uint32_t si = wave_append(wantShadow, shadowCountOut);
-        if (wantShadow) P.shadowQueue[si] = slot;
+        contMask |= (cont ? 1u : 0u) << item;
+        shadowMask |= (wantShadow ? 1u : 0u) << item;
+      }
+      // compaction: next bounce's path queue and this bounce's shadow queue, one atomic each per block
+      bool flag[2][RT_ITEMS];
+      uint32_t idx[2][RT_ITEMS];
+#pragma unroll
+      for (int k = 0; k < RT_ITEMS; k++) { flag[0][k] = (contMask >> k) & 1u; flag[1][k] = (shadowMask >> k) & 1u; }
+      uint32_t* const ctr[2] = {countOut, shadowCountOut};
+      block_append<2>(flag, ctr, idx, ldsAppend);
+#pragma unroll
+      for (int k = 0; k < RT_ITEMS; k++) {
+          if (flag[0][k] | flag[1][k]) {
+              uint32_t i = ch * chunk + (uint32_t)k * RT_BLOCK + threadIdx.x;
+              uint32_t slot = queue ? queue[i] : i;
+              if (flag[0][k]) queueOut[idx[0][k]] = slot;
+              if (flag[1][k]) P.shadowQueue[idx[1][k]] = slot;
+          }
+      }
     }
-    for (int off = 32; off > 0; off >>= 1) skipped += __shfl_down(skipped, off, 64);
-    if ((threadIdx.x & 63) == 0 && skipped) atomicAdd(&stats->rays_shadow_skipped, (unsigned long long)skipped);
+    // ray counters: wave shuffle -> LDS -> one global atomic per block
+    for (int off = 32; off > 0; off >>= 1) { skipped += __shfl_down(skipped, off, 64); pending += __shfl_down(pending, off, 64); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { if (pending) atomicAdd(&ldsCount[0], pending); if (skipped) atomicAdd(&ldsCount[1], skipped); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (ldsCount[0]) atomicAdd(&stats->rays_shadow, (unsigned long long)ldsCount[0]);
+        if (ldsCount[1]) atomicAdd(&stats->rays_shadow_skipped, (unsigned long long)ldsCount[1]);
+    }
 }
 
-// shader.comp:453-484 + the accumulate of 521, lights in order.
+// shader.comp:453-484: the shadow lineCast of every log entry awaiting one; the entry becomes "add" (2) or "none" (0).
 template <bool EXACT, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
-                                                     DeviceStats* stats) {
+                                                     int bounce, DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    const Stack stk = make_stack(lds, P);
     uint32_t n = *count;
-    uint32_t nNodes = 0, nTris = 0, nRays = 0;
+    uint32_t nNodes = 0, nTris = 0;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         uint32_t slot = P.shadowQueue[i];
         float4 o4 = P.rayO[slot], h4 = P.hit[slot];
         v3 o = mk(o4.x, o4.y, o4.z), hitLoc = mk(h4.x, h4.y, h4.z);
-        float4 acc = P.accum[slot];
-        bool dirty = false;
+        float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;
         for (int l = 0; l < F.numLights; l++) {
-            float4 pe = P.pend[(size_t)l * P.nslots + slot];
-            if (pe.w != 1.f) continue;
+            float* wp = &logp[(size_t)l * P.nslots].w;
+            if (*wp != 1.f) continue;
             const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
             float4 L0 = lp[0], L1 = lp[1];
             uint32_t ltype = __float_as_uint(L1.w);
@@ -582,37 +673,56 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
                 dirToLight = normalize3(toL);
                 distToLight = length3(toL);
             } else dirToLight = -mk(L1.x, L1.y, L1.z);
-            nRays++;
             bool occ;
             if (EXACT) {
                 HitRec best;
-                bool h = closest_hit<true, COUNT>(S, o, dirToLight, lds + threadIdx.x, best, nNodes, nTris);
+                bool h = closest_hit<true, COUNT>(S, o, dirToLight, stk, best, nNodes, nTris);
                 if (ltype == 0u) { v3 dl = best.loc - hitLoc; occ = h && (sqrtf(dot3(dl, dl)) < distToLight); }
                 else occ = h;
             } else {
-                occ = occluded_fast<COUNT>(S, o, dirToLight, (int)ltype, hitLoc, distToLight, lds + threadIdx.x, nNodes, nTris);
+                occ = occluded_fast<COUNT>(S, o, dirToLight, (int)ltype, hitLoc, distToLight, stk, nNodes, nTris);
             }
-            if (!occ) { acc.x += pe.x; acc.y += pe.y; acc.z += pe.z; dirty = true; }
-        }
-        if (dirty) P.accum[slot] = make_float4(acc.x, acc.y, acc.z, 1.f);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        nRays += __shfl_down(nRays, off, 64);
-        if (COUNT) { nNodes += __shfl_down(nNodes, off, 64); nTris += __shfl_down(nTris, off, 64); }
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (nRays) atomicAdd(&stats->rays_shadow, (unsigned long long)nRays);
-        if (COUNT && (nNodes | nTris)) {
-            atomicAdd(&stats->shadow_node_visits, (unsigned long long)nNodes);
-            atomicAdd(&stats->shadow_tri_tests, (unsigned long long)nTris);
+            *wp = occ ? 0.f : 2.f;
         }
     }
+    if (COUNT) {
+        __shared__ uint32_t red[2];
+        if (threadIdx.x < 2) red[threadIdx.x] = 0;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) { nNodes += __shfl_down(nNodes, off, 64); nTris += __shfl_down(nTris, off, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nNodes); atomicAdd(&red[1], nTris); }
+        __syncthreads();
+        if (threadIdx.x == 0 && (red[0] | red[1])) {
+            atomicAdd(&stats->shadow_node_visits, (unsigned long long)red[0]);
+            atomicAdd(&stats->shadow_tri_tests, (unsigned long long)red[1]);
+        }
+    }
+}
+
+// shader.comp:332 and 521: `color.rgb += ...` replayed per pixel in the shader's own order — samples ascending,
+// bounces ascending, lights ascending — from the pass's contribution log.  One thread per pixel slot.
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathBuffers P, int samplesInPass, int maxBounces) {
+    uint32_t ps = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (ps >= P.slotsPerSample) return;
+    float4 acc = P.accum[ps];
+    for (int sm = 0; sm < samplesInPass; sm++) {
+        uint32_t slot = (uint32_t)sm * P.slotsPerSample + ps;
+        uint32_t d = P.depth[slot];
+        for (uint32_t b = 0; b < d; b++) {
+            const float4* logp = P.contrib + (size_t)b * P.lightSlots * P.nslots + slot;
+            for (uint32_t l = 0; l < P.lightSlots; l++) {
+                float4 e = logp[(size_t)l * P.nslots];
+                if (e.w == 2.f) { acc.x = acc.x + e.x; acc.y = acc.y + e.y; acc.z = acc.z + e.z; }
+            }
+        }
+    }
+    P.accum[ps] = acc;
 }
 
 // Image defaults the shader stores for pixels whose primary ray misses (shader.comp:299-301,534-536).
 __global__ __launch_bounds__(RT_BLOCK) void k_init_frame(FrameParams F, PathBuffers P, float4* imgAlbedo, float4* imgNormal, float4* imgDepth) {
     uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (slot >= P.nslots) return;
+    if (slot >= P.slotsPerSample) return;
     P.accum[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
     int px, py;
     slot_to_pixel(F, slot, &px, &py);
@@ -627,7 +737,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_init_frame(FrameParams F, PathBuff
 // shader.comp:533 — un-swizzle the tile-ordered accumulators into the row-major colour image.
 __global__ __launch_bounds__(RT_BLOCK) void k_finalize(FrameParams F, PathBuffers P, float4* imgColor) {
     uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (slot >= P.nslots) return;
+    if (slot >= P.slotsPerSample) return;
     int px, py;
     slot_to_pixel(F, slot, &px, &py);
     if (px < F.rx + F.rw && py < F.ry + F.rh) {

@@ -95,6 +95,7 @@ static_assert(sizeof(CShade) == 112, "CShade");
 struct TexDesc { const uint8_t* rgba8; uint32_t width, height; };
 
 #define RT_MAX_LIGHTS 8
+#define RT_MAX_STREAMS 8
 #define RT_LDS_STACK 16          // per-lane stack entries kept in LDS
 #define RT_SPILL_STACK 48        // further entries in scratch; total = 64 = shader.comp:246
 
@@ -130,6 +131,7 @@ struct DeviceStats {
     unsigned long long rays_primary, rays_bounce, rays_shadow, rays_shadow_skipped;
     unsigned long long node_visits, tri_tests;                 // closest-hit (k_extend) traversal
     unsigned long long shadow_node_visits, shadow_tri_tests;   // shadow (k_shadow) traversal
+    unsigned long long max_ray_steps;                          // most node visits + triangle tests by one closest-hit ray
 };
 
 }  // namespace rt
