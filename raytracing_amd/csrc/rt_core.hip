@@ -250,7 +250,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     // kernels, bounded by a slot budget.
     const uint32_t maxB = (uint32_t)c->maxBounces;
     uint32_t S_ = (uint32_t)(c->samplesPerPass < 1 ? 1 : c->samplesPerPass);
-    const uint64_t slotBudget = 1ull << 25;
+    const uint64_t slotBudget = 1ull << 27;   // ~210 B of path state + log per slot
     if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
     if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
     const uint32_t nslots = S_ * sps;
