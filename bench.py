@@ -44,13 +44,6 @@ def parse():
     return ap.parse_args()
 
 
-class DevImage:
-    """Zero-copy view of a core image for torch (RCCL reduce) via __cuda_array_interface__."""
-
-    def __init__(self, ptr, h, w):
-        self.__cuda_array_interface__ = {"shape": (h, w, 4), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-
 def cpu_baseline(args, gpu_image):
     """Oracle (CPU restatement of shader.comp, OpenMP) on a bounded sample of the same workload:
     the first s samples r in [0, s) of the frame, s chosen to fill ~args.cpu_seconds."""
@@ -92,7 +85,7 @@ def main():
 
     from raytracing_amd import ComputeShader
     from raytracing_amd import scene as S
-    from raytracing_amd.distributed import sample_range
+    from raytracing_amd.distributed import image_tensor, sample_range
 
     cs = ComputeShader(device=dev, rank=rank, world_size=world)
     S.Scene.LoadScene(cs, args.scene, MODELS)
@@ -107,7 +100,7 @@ def main():
         cs.setInt("blocksPerCU", args.blocks_per_cu)
     S.set_camera(cs, S.DEFAULT_CAMERA[0], S.DEFAULT_CAMERA[1], W, H, 45.0)
     r0, r1 = sample_range(args.spp, rank, world)
-    color = torch.as_tensor(DevImage(cs.image_device_ptr(0), H, W), device="cuda:%d" % dev)
+    color = image_tensor(cs, 0)
 
     def barrier():
         torch.cuda.synchronize()

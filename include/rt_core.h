@@ -95,7 +95,8 @@ rt_status rt_create_texture(rt_ctx* ctx, const uint8_t* rgba8, uint32_t width, u
 rt_status rt_render_frame(rt_ctx* ctx);
 /* Partition form used by the multi-GPU driver (no reference counterpart; the reference is single-GPU):
  * traces pixels [x,x+w) x [y,y+h) and samples [spp_begin, spp_end) of samplesPerPixel.  Pixels outside the
- * region are zero in the color image; AOV images are written only when spp_begin == 0. */
+ * region are zero in all four images; the AOV images (albedo, normal, depth) are written when spp_begin == 0 and
+ * are all-zero otherwise, so partial renders merge with one element-wise sum. */
 rt_status rt_render_region(rt_ctx* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
                            uint32_t spp_begin, uint32_t spp_end);
 

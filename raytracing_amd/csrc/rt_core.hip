@@ -273,8 +273,10 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     float4* iDep = aov ? (float4*)c->img[3].p : nullptr;
     int32_t* pTri = aov ? (int32_t*)c->primTri.p : nullptr;
     float* pHit = aov ? (float*)c->primHit.p : nullptr;
+    // AOV images: zero everywhere, then written by the call whose sample range contains r = 0 (so that partial
+    // renders of disjoint regions / sample ranges can be merged with one sum)
+    for (int i = 1; i < 4; i++) HIPCHK(c, hipMemsetAsync(c->img[i].p, 0, (size_t)c->width * c->height * 16, st));
     if (aov) {
-        for (int i = 1; i < 4; i++) HIPCHK(c, hipMemsetAsync(c->img[i].p, 0, (size_t)c->width * c->height * 16, st));
         HIPCHK(c, hipMemsetAsync(c->primTri.p, 0xFF, (size_t)c->width * c->height * 4, st));
         HIPCHK(c, hipMemsetAsync(c->primHit.p, 0, (size_t)c->width * c->height * 12, st));
     }

@@ -43,3 +43,29 @@ def reduce_color(color_tensor, dst=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(color_tensor, dst=dst, op=dist.ReduceOp.SUM)
     return color_tensor
+
+
+class DeviceImage:
+    """Zero-copy torch view of a core image (W*H*4 floats in HBM) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, height, width):
+        self.__cuda_array_interface__ = {"shape": (height, width, 4), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def image_tensor(cs, image=0):
+    import torch
+    return torch.as_tensor(DeviceImage(cs.image_device_ptr(image), cs.height, cs.width), device="cuda:%d" % torch.cuda.current_device())
+
+
+def render_frame_distributed(cs, spp, rank, world, band_ranks=1, dst=0, aovs=False):
+    """One frame on `world` GPUs: this rank traces its (row band, sample range) shard with rt_render_region, then the
+    colour buffers are summed onto `dst` (and, if asked, the AOV buffers, which are zero on ranks not owning r = 0)."""
+    x, y, w, h, r0, r1 = partition(cs.width, cs.height, spp, rank, world, band_ranks)
+    if h > 0 and r1 > r0:
+        cs.dispatch_region(x, y, w, h, r0, r1)
+    else:
+        cs.dispatch_region(0, 0, cs.width, min(8, cs.height), 0, 0)   # empty shard: clears the images, traces nothing
+    if world > 1:
+        for img in ((0, 1, 2, 3) if aovs else (0,)):
+            reduce_color(image_tensor(cs, img), dst)
+    return (x, y, w, h, r0, r1)

@@ -1,0 +1,184 @@
+"""GPU: behaviour of the C ABI around the hot path — regions / sample ranges (the multi-GPU partition), invariance to
+the number of samples in flight, ragged image sizes, error reporting, the host loader on the GPU, 8-bit frames."""
+import numpy as np
+import pytest
+
+from tests.util import bits, same_floats, setup_core
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene4(oracle_lib, models_root):
+    return oracle_lib.load_scene(models_root, 4)
+
+
+@pytest.fixture(scope="module")
+def scene7(oracle_lib, models_root):
+    return oracle_lib.load_scene(models_root, 7)
+
+
+def _render(cs, region=None, spp_range=None):
+    if region is None and spp_range is None:
+        cs.dispatch()
+    else:
+        x, y, w, h = region or (0, 0, cs.width, cs.height)
+        r0, r1 = spp_range
+        cs.dispatch_region(x, y, w, h, r0, r1)
+    return [cs.get_image(k) for k in range(4)]
+
+
+def test_ragged_size_and_single_sample(oracle_lib, scene4):
+    """Sizes that are not multiples of the 8x8 ray tile (dead slots), spp = 1, 1 bounce."""
+    from raytracing_amd import ComputeShader
+    for W, H, spp, b in ((50, 37, 3, 4), (9, 5, 1, 1), (64, 8, 2, 2)):
+        want = oracle_lib.render(scene4, oracle_lib.make_params(scene4, W, H, spp, b, math_mode=1))
+        cs = ComputeShader()
+        setup_core(cs, scene4, W, H, spp, b)
+        imgs = _render(cs)
+        for k, name in enumerate(("color", "albedo", "normal", "depth")):
+            assert same_floats(imgs[k], want[name]).all(), (W, H, name)
+        st = cs.stats()
+        assert st["rays_primary"] == W * H * spp
+        cs.Delete()
+
+
+def test_samples_per_pass_does_not_change_the_image(oracle_lib, scene7):
+    from raytracing_amd import ComputeShader
+    W, H, spp, b = 64, 40, 6, 8
+    cs = ComputeShader()
+    setup_core(cs, scene7, W, H, spp, b)
+    ref_img = None
+    for S in (1, 2, 4, 6, 32):
+        cs.setInt("samplesPerPass", S)
+        img = _render(cs)[0]
+        if ref_img is None:
+            ref_img = img
+            want = oracle_lib.render(scene7, oracle_lib.make_params(scene7, W, H, spp, b, math_mode=1))
+            assert same_floats(img, want["color"]).all()
+        else:
+            assert same_floats(img, ref_img).all(), S
+    cs.Delete()
+
+
+def test_region_is_bit_identical_and_sample_ranges_sum(oracle_lib, scene4):
+    from raytracing_amd import ComputeShader
+    W, H, spp, b = 64, 48, 4, 6
+    cs = ComputeShader()
+    setup_core(cs, scene4, W, H, spp, b)
+    full = _render(cs)
+    # row band [16, 40): identical inside, zero outside, all four images
+    band = _render(cs, region=(0, 16, W, 24), spp_range=(0, spp))
+    for k in range(4):
+        assert same_floats(band[k][16:40], full[k][16:40]).all()
+        assert (band[k][:16] == 0).all() and (band[k][40:] == 0).all()
+    # a window not aligned to the tile grid
+    win = _render(cs, region=(5, 3, 30, 21), spp_range=(0, spp))
+    assert same_floats(win[0][3:24, 5:35], full[0][3:24, 5:35]).all()
+    # sample ranges: colour sums to the full frame up to float re-association; AOVs only from the range holding r = 0
+    a = _render(cs, spp_range=(0, 1))
+    c = _render(cs, spp_range=(1, spp))
+    assert np.allclose(a[0][..., :3] + c[0][..., :3], full[0][..., :3], rtol=1e-5, atol=1e-6)
+    for k in (1, 2, 3):
+        assert same_floats(a[k], full[k]).all() and (c[k] == 0).all()
+    # empty sample range: clears, traces nothing
+    e = _render(cs, spp_range=(2, 2))
+    assert (e[0][..., :3] == 0).all() and cs.stats()["rays_primary"] == 0
+    cs.Delete()
+
+
+def test_zero_bounces_and_no_lights(oracle_lib, scene4):
+    from raytracing_amd import ComputeShader
+    W, H = 32, 24
+    cs = ComputeShader()
+    setup_core(cs, scene4, W, H, 2, 0)
+    img = _render(cs)
+    assert (img[0][..., :3] == 0).all() and (img[0][..., 3] == 1).all()      # maxBounces = 0: the loop body never runs
+    assert (img[2][..., :3] == 0.5).all()
+    cs.setInt("maxBounces", 3)
+    cs.setInt("numLights", 0)
+    got = _render(cs)[0]
+    p = oracle_lib.make_params(scene4, W, H, 2, 3, math_mode=1)
+    p.numLights = 0
+    want = oracle_lib.render(scene4, p)
+    assert same_floats(got, want["color"]).all()
+    assert cs.stats()["rays_shadow"] == 0
+    cs.Delete()
+
+
+def test_errors_are_reported_not_crashes(scene4):
+    from raytracing_amd import ComputeShader, SSBO
+    from raytracing_amd.core import RtError
+    cs = ComputeShader()
+    with pytest.raises(RtError) as e:
+        cs.dispatch()
+    assert e.value.status == 3                      # RT_ERR_NOT_READY: no image size
+    cs.resize(16, 16)
+    with pytest.raises(RtError) as e:
+        cs.dispatch()
+    assert e.value.status == 3                      # slots missing
+    with pytest.raises(RtError) as e:
+        SSBO.Bind(cs, np.zeros(10, np.uint8), 10, 3)
+    assert e.value.status == 2                      # not a multiple of 48
+    with pytest.raises(RtError):
+        SSBO.Bind(cs, np.zeros(48, np.uint8), 48, 9)
+    setup_core(cs, scene4, 16, 16, 1, 1)
+    bad = scene4.triangles.copy()
+    bad["indices"][0, 0] = 10 ** 7
+    SSBO.Bind(cs, bad, bad.nbytes, 4)
+    with pytest.raises(RtError) as e:
+        cs.dispatch()
+    assert e.value.status == 5                      # RT_ERR_SCENE: vertex index out of range, caught on the host
+    nodes = scene4.nodes.copy()
+    nodes["children"][0, 1] = 0                     # cycle
+    SSBO.Bind(cs, scene4.triangles, scene4.triangles.nbytes, 4)
+    SSBO.Bind(cs, nodes, nodes.nbytes, 3)
+    with pytest.raises(RtError) as e:
+        cs.dispatch()
+    assert e.value.status == 5
+    with pytest.raises(RtError):
+        cs.dispatch_region(0, 0, 17, 16, 0, 1)      # region outside the image
+    cs.setInt("projection", 1)                      # unknown uniform names are ignored like GL location -1
+    cs.setMat4("invView", np.eye(4))
+    cs.Delete()
+
+
+@pytest.mark.parametrize("scene_id", [2, 4, 7])
+def test_host_loader_end_to_end(oracle_lib, models_root, scene_id):
+    """Scene::LoadScene through the C++ host layer on the GPU (textures included) equals the oracle-side set-up."""
+    from raytracing_amd import ComputeShader
+    from raytracing_amd import scene as S
+    W, H, spp, b = 80, 48, 2, 6
+    cs = ComputeShader()
+    S.Scene.LoadScene(cs, scene_id, models_root)
+    cs.resize(W, H)
+    cs.setInt("samplesPerPixel", spp)
+    cs.setInt("maxBounces", b)
+    S.set_camera(cs, S.DEFAULT_CAMERA[0], S.DEFAULT_CAMERA[1], W, H, 45.0)
+    cs.dispatch()
+    sc = oracle_lib.load_scene(models_root, scene_id)
+    want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
+    assert same_floats(cs.get_image(0), want["color"]).all()
+    # Renderer::NextFrame's 8-bit conversion: clamp, truncate, vertical flip
+    rgba8 = S.frame_rgba8(cs)
+    f = np.nan_to_num(np.clip(want["color"][::-1], 0, 1), nan=0.0)
+    assert np.array_equal(rgba8, (f * np.float32(255)).astype(np.uint8))
+    # orbit camera (config 5's path) through the host helper renders and differs from the default view
+    pos, ori = S.orbit_camera(30)
+    S.set_camera(cs, pos, ori, W, H, 45.0)
+    cs.dispatch()
+    cam = (pos, ori)
+    want2 = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, camera=cam, math_mode=1))
+    assert same_floats(cs.get_image(0), want2["color"]).all()
+    cs.Delete()
+
+
+def test_write_image_and_device_pointer(scene4):
+    from raytracing_amd import ComputeShader
+    cs = ComputeShader()
+    setup_core(cs, scene4, 16, 8, 1, 1)
+    img = np.random.default_rng(0).random((8, 16, 4), dtype=np.float32)
+    cs.set_image(0, img)                             # glTexSubImage2D write-back (main.cpp:184)
+    assert np.array_equal(cs.get_image(0), img)
+    assert cs.image_device_ptr(0) != 0 and cs.image_device_ptr(3) != cs.image_device_ptr(0)
+    cs.Delete()

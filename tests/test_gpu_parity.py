@@ -98,3 +98,51 @@ def test_trace_rays_matches_linecast(oracle_lib, scenes):
             m = tri >= 0
             assert np.array_equal(bits(hit)[m], bits(want_hit)[m])
         cs.Delete()
+
+
+@pytest.mark.parametrize("scene_id,spp,bounces", [(4, 4, 8), (7, 4, 16), (2, 2, 16)])
+def test_full_size_culled_traversal_equals_reference_order(scenes, scene_id, spp, bounces):
+    """BASELINE sizes (1920x1080), where the CPU oracle is too slow to be the checker: the culled / ordered traversal
+    (traversalMode 0, the shipped path) must give the same four images, bit for bit, as the exhaustive reference-order
+    traversal (traversalMode 1) that the small-size tests pin to the oracle — every ray of every bounce takes part."""
+    from raytracing_amd import ComputeShader
+    sc = scenes(scene_id)
+    W, H = 1920, 1080
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, bounces)
+    out = {}
+    for mode in (1, 0):
+        cs.setInt("traversalMode", mode)
+        cs.dispatch()
+        out[mode] = ([cs.get_image(k) for k in range(4)], cs.primary_hits(), cs.stats())
+    for k in range(4):
+        assert same_floats(out[0][0][k], out[1][0][k]).all(), "image %d differs between traversal modes" % k
+    assert np.array_equal(out[0][1][0], out[1][1][0])
+    for key in ("rays_primary", "rays_bounce", "rays_shadow", "rays_shadow_skipped"):
+        assert out[0][2][key] == out[1][2][key]
+    assert out[0][2]["rays_primary"] == W * H * spp
+    cs.Delete()
+
+
+def test_million_random_rays_both_modes(scenes):
+    from raytracing_amd import ComputeShader
+    rng = np.random.default_rng(11)
+    for scene_id in (4, 7):
+        sc = scenes(scene_id)
+        n = 1 << 20
+        lo = sc.nodes["minLoc"][0] - 2.0
+        hi = sc.nodes["maxLoc"][0] + 2.0
+        o = (lo + rng.random((n, 3)) * (hi - lo)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d[::17, rng.integers(0, 3)] = 0.0
+        cs = ComputeShader()
+        setup_core(cs, sc, 8, 8, 1, 1)
+        cs.setInt("traversalMode", 1)
+        t1, h1 = cs.trace_rays(o, d)
+        cs.setInt("traversalMode", 0)
+        t0, h0 = cs.trace_rays(o, d)
+        assert np.array_equal(t0, t1)
+        m = t0 >= 0
+        assert m.sum() > n // 100
+        assert np.array_equal(bits(h0)[m], bits(h1)[m])
+        cs.Delete()
