@@ -90,24 +90,41 @@ __device__ __forceinline__ void slot_to_pixel(const FrameParams& F, uint32_t slo
 
 // ---------------------------------------------------------------------------------------------
 // shader.comp:171-184 — same float sequence; also returns tEnter for ordering / culling.
+// FAST: the hardware min/max (v_min_f32 / v_max3_f32 ...).  They equal the GLSL selects `y<x?y:x` / `x<y?y:x`
+// whenever no operand is NaN (a +-0 pick cannot change the two comparisons below), and a NaN can only appear here
+// as 0 * inf, i.e. for a ray with a zero / non-finite direction component or a non-finite origin.  Waves holding
+// such a ray run the select form (ray_is_plain below), so both forms return identical results.
+template <bool FAST>
 __device__ __forceinline__ bool slab(v3 o, v3 inv, const float* lo, const float* hi, float* tEnterOut) {
     float t0x = (lo[0] - o.x) * inv.x, t0y = (lo[1] - o.y) * inv.y, t0z = (lo[2] - o.z) * inv.z;
     float t1x = (hi[0] - o.x) * inv.x, t1y = (hi[1] - o.y) * inv.y, t1z = (hi[2] - o.z) * inv.z;
-    float tminx = gmin(t0x, t1x), tminy = gmin(t0y, t1y), tminz = gmin(t0z, t1z);
-    float tmaxx = gmax(t0x, t1x), tmaxy = gmax(t0y, t1y), tmaxz = gmax(t0z, t1z);
-    float tEnter = gmax(gmax(tminx, tminy), tminz);
-    float tExit = gmin(gmin(tmaxx, tmaxy), tmaxz);
+    float tEnter, tExit;
+    if (FAST) {
+        tEnter = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+        tExit = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    } else {
+        float tminx = gmin(t0x, t1x), tminy = gmin(t0y, t1y), tminz = gmin(t0z, t1z);
+        float tmaxx = gmax(t0x, t1x), tmaxy = gmax(t0y, t1y), tmaxz = gmax(t0z, t1z);
+        tEnter = gmax(gmax(tminx, tminy), tminz);
+        tExit = gmin(gmin(tmaxx, tmaxy), tmaxz);
+    }
     *tEnterOut = tEnter;
     return tExit >= tEnter && tExit >= 0.0f;
 }
 
+// true when the ray can never produce a NaN in a slab test: finite origin, finite non-zero direction components
+__device__ __forceinline__ bool ray_is_plain(v3 o, v3 d) {
+    const float big = 3.0e38f;
+    bool od = fabsf(o.x) < big && fabsf(o.y) < big && fabsf(o.z) < big;
+    bool dd = fabsf(d.x) < big && fabsf(d.y) < big && fabsf(d.z) < big && d.x != 0.f && d.y != 0.f && d.z != 0.f;
+    return od && dd;
+}
+
 struct HitRec { float dist; float t; int idx; int ref; v3 loc; };
 
-// shader.comp:104-125 + 269-276 on a pre-transformed triangle.
+// shader.comp:104-125 + 269-276 on a pre-transformed triangle (A, B, C = the record's three 16-byte words).
 template <bool EXACT>
-__device__ __forceinline__ void test_tri(const CTri* __restrict__ tris, int idx, v3 o, v3 d, HitRec& best) {
-    const float4* p = reinterpret_cast<const float4*>(tris + idx);
-    float4 A = p[0], B = p[1], C = p[2];
+__device__ __forceinline__ void test_tri(float4 A, float4 B, float4 C, int idx, v3 o, v3 d, HitRec& best) {
     v3 v0 = mk(A.x, A.y, A.z), e1 = mk(A.w, B.x, B.y), e2 = mk(B.z, B.w, C.x);
     v3 pv = cross3(d, e2);
     float det = dot3(e1, pv);
@@ -158,12 +175,14 @@ __device__ __forceinline__ Stack make_stack(uint2* ldsBase, const struct PathBuf
     return st;
 }
 
-// Closest hit == lineCast (shader.comp:243-290).
+#define RT_DONE ((int)0x80000000)   // traversal finished (never a valid leaf code: codes are < 2^31)
+
+// Closest hit == lineCast (shader.comp:243-290), "while-while" form: an inner loop that only descends internal
+// nodes and a leaf step that only tests triangles, so a wave executes each body with the lanes that need it instead
+// of both bodies per step.
 //   EXACT:  reference order (right child first), no culling, leaf children always entered.
 //   !EXACT: near child first, distance culling with slack, padded leaf boxes.  Same winner: DESIGN.md.
-//   ANYHIT: stop at the first accepted hit with t-independent predicate `accept` (sun: any hit;
-//           point light: distance(hit, shadeLoc) < distToLight), see k_shadow.
-template <bool EXACT, bool COUNT>
+template <bool EXACT, bool COUNT, bool FAST>
 __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, const Stack& stk, HitRec& best,
                                             uint32_t& nNodes, uint32_t& nTris) {
     best.dist = 3.40282347e+38f; best.t = __int_as_float(0x7f800000); best.idx = -1; best.ref = -1;
@@ -171,11 +190,23 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, cons
     v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float te;
     if (COUNT) nNodes++;
-    if (!slab(o, inv, S.rootLo, S.rootHi, &te)) return false;
+    if (!slab<FAST>(o, inv, S.rootLo, S.rootHi, &te)) return false;
     int sp = 0;
     int cur = S.rootChild;
-    while (true) {
-        if (cur >= 0) {
+    auto popNext = [&]() {
+        cur = RT_DONE;
+        while (sp > 0) {
+            uint2 e = stk.pop(sp);
+            if (!EXACT) {
+                float lim = best.t + best.t * 1e-4f + S.cullAbs;
+                if (__uint_as_float(e.y) > lim) continue;
+            }
+            cur = (int)e.x;
+            break;
+        }
+    };
+    while (cur != RT_DONE) {
+        while (cur >= 0) {
             const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
             float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             if (COUNT) nNodes++;
@@ -183,54 +214,41 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, cons
             float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
             int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             float t0, t1;
-            bool p0 = slab(o, inv, lo0, hi0, &t0);
-            bool p1 = slab(o, inv, lo1, hi1, &t1);
+            bool p0 = slab<FAST>(o, inv, lo0, hi0, &t0);
+            bool p1 = slab<FAST>(o, inv, lo1, hi1, &t1);
             if (EXACT) {
-                // a leaf child's own box is never tested by the reference (Q2): enter unconditionally
+                // a leaf child's own box is never tested by the reference (Q2): enter unconditionally;
+                // the reference pops children.y first (shader.comp:281-284)
                 p0 = p0 || (c0 < 0);
                 p1 = p1 || (c1 < 0);
-                // reference pops children.y first (shader.comp:281-284)
-                if (p0 && p1) {
-                    uint2 e; e.x = (uint32_t)c0; e.y = 0u;
-                    stk.push(sp, e);
-                    cur = c1; continue;
-                }
-                if (p1) { cur = c1; continue; }
-                if (p0) { cur = c0; continue; }
+                if (p0 && p1) { uint2 e; e.x = (uint32_t)c0; e.y = 0u; stk.push(sp, e); cur = c1; }
+                else if (p1) cur = c1;
+                else if (p0) cur = c0;
+                else popNext();
             } else {
                 float lim = best.t + best.t * 1e-4f + S.cullAbs;
                 p0 = p0 && !(t0 > lim);
                 p1 = p1 && !(t1 > lim);
                 if (p0 && p1) {
                     bool swap = t1 < t0;
-                    int nearC = swap ? c1 : c0, farC = swap ? c0 : c1;
-                    float farT = swap ? t0 : t1;
-                    uint2 e; e.x = (uint32_t)farC; e.y = __float_as_uint(farT);
+                    uint2 e; e.x = (uint32_t)(swap ? c0 : c1); e.y = __float_as_uint(swap ? t0 : t1);
                     stk.push(sp, e);
-                    cur = nearC; continue;
-                }
-                if (p0) { cur = c0; continue; }
-                if (p1) { cur = c1; continue; }
+                    cur = swap ? c1 : c0;
+                } else if (p0) cur = c0;
+                else if (p1) cur = c1;
+                else popNext();
             }
-        } else {
+        }
+        if (cur != RT_DONE) {
             int code = -cur - 1;
             int first = code >> 3, cnt = code & 7;
+            const float4* tp = reinterpret_cast<const float4*>(S.tris + first);
             for (int k = 0; k < cnt; k++) {
                 if (COUNT) nTris++;
-                test_tri<EXACT>(S.tris, first + k, o, d, best);
+                test_tri<EXACT>(tp[3 * k], tp[3 * k + 1], tp[3 * k + 2], first + k, o, d, best);
             }
+            popNext();
         }
-        // pop
-        bool got = false;
-        while (sp > 0) {
-            uint2 e = stk.pop(sp);
-            if (!EXACT) {
-                float lim = best.t + best.t * 1e-4f + S.cullAbs;
-                if (__uint_as_float(e.y) > lim) continue;
-            }
-            cur = (int)e.x; got = true; break;
-        }
-        if (!got) break;
     }
     return best.idx >= 0;
 }
@@ -239,19 +257,20 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, cons
 // kind 0 (point): occluded when the closest hit H has distance(H, shadeLoc) < distToLight
 // (shader.comp:467-471).  In traversalMode 0 the first hit satisfying that predicate ends the walk and
 // boxes entered beyond distToLight (+slack) are skipped; traversalMode 1 runs the full closest-hit.
-template <bool COUNT>
+template <bool COUNT, bool FAST>
 __device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, int kind, v3 shadeLoc, float distToLight,
                                               const Stack& stk, uint32_t& nNodes, uint32_t& nTris) {
     v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float te;
     if (COUNT) nNodes++;
-    if (!slab(o, inv, S.rootLo, S.rootHi, &te)) return false;
+    if (!slab<FAST>(o, inv, S.rootLo, S.rootHi, &te)) return false;
     // For point lights |d| = 1 so t ~ distance from o; o is within ~1e-5*|n| of shadeLoc.
     float lim = (kind == 0) ? (distToLight + distToLight * 1e-3f + S.cullAbs * 4.0f) : __int_as_float(0x7f800000);
     int sp = 0;
     int cur = S.rootChild;
-    while (true) {
-        if (cur >= 0) {
+    bool occ = false;
+    while (cur != RT_DONE) {
+        while (cur >= 0) {
             const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
             float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             if (COUNT) nNodes++;
@@ -259,34 +278,33 @@ __device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, in
             float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
             int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             float t0, t1;
-            bool p0 = slab(o, inv, lo0, hi0, &t0) && !(t0 > lim);
-            bool p1 = slab(o, inv, lo1, hi1, &t1) && !(t1 > lim);
-            if (p0 && p1) {
-                uint2 e; e.x = (uint32_t)c1; e.y = 0u;
-                stk.push(sp, e);
-                cur = c0; continue;
-            }
-            if (p0) { cur = c0; continue; }
-            if (p1) { cur = c1; continue; }
-        } else {
+            bool p0 = slab<FAST>(o, inv, lo0, hi0, &t0) && !(t0 > lim);
+            bool p1 = slab<FAST>(o, inv, lo1, hi1, &t1) && !(t1 > lim);
+            if (p0 && p1) { uint2 e; e.x = (uint32_t)c1; e.y = 0u; stk.push(sp, e); cur = c0; }
+            else if (p0) cur = c0;
+            else if (p1) cur = c1;
+            else if (sp > 0) cur = (int)stk.pop(sp).x;
+            else cur = RT_DONE;
+        }
+        if (cur != RT_DONE) {
             int code = -cur - 1;
             int first = code >> 3, cnt = code & 7;
+            const float4* tp = reinterpret_cast<const float4*>(S.tris + first);
             for (int k = 0; k < cnt; k++) {
                 if (COUNT) nTris++;
                 HitRec h; h.dist = 3.40282347e+38f; h.idx = -1; h.t = 0.f; h.ref = -1; h.loc = mk(0.f, 0.f, 0.f);
-                test_tri<true>(S.tris, first + k, o, d, h);
+                test_tri<true>(tp[3 * k], tp[3 * k + 1], tp[3 * k + 2], first + k, o, d, h);
                 if (h.idx >= 0) {
-                    if (kind == 1) return true;
-                    v3 dl = h.loc - shadeLoc;
-                    if (sqrtf(dot3(dl, dl)) < distToLight) return true;
+                    if (kind == 1) occ = true;
+                    else { v3 dl = h.loc - shadeLoc; if (sqrtf(dot3(dl, dl)) < distToLight) occ = true; }
                 }
             }
+            if (occ) cur = RT_DONE;
+            else if (sp > 0) cur = (int)stk.pop(sp).x;
+            else cur = RT_DONE;
         }
-        if (sp == 0) break;
-        uint2 e = stk.pop(sp);
-        cur = (int)e.x;
     }
-    return false;
+    return occ;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,7 +352,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, PathBuffers P,
         if (__float_as_uint(o4.w) & RT_FLAG_DEAD) { P.hit[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-2)); continue; }
         HitRec best;
         uint32_t before = nNodes + nTris;
-        closest_hit<EXACT, COUNT>(S, mk(o4.x, o4.y, o4.z), mk(d4.x, d4.y, d4.z), stk, best, nNodes, nTris);
+        v3 ro = mk(o4.x, o4.y, o4.z), rd = mk(d4.x, d4.y, d4.z);
+        if (__all(ray_is_plain(ro, rd))) closest_hit<EXACT, COUNT, true>(S, ro, rd, stk, best, nNodes, nTris);
+        else closest_hit<EXACT, COUNT, false>(S, ro, rd, stk, best, nNodes, nTris);
         if (COUNT) { uint32_t steps = nNodes + nTris - before; if (steps > maxSteps) maxSteps = steps; }
         P.hit[slot] = make_float4(best.loc.x, best.loc.y, best.loc.z, __int_as_float(best.ref));
     }
@@ -674,13 +694,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
                 distToLight = length3(toL);
             } else dirToLight = -mk(L1.x, L1.y, L1.z);
             bool occ;
+            const bool plain = __all(ray_is_plain(o, dirToLight));
             if (EXACT) {
                 HitRec best;
-                bool h = closest_hit<true, COUNT>(S, o, dirToLight, stk, best, nNodes, nTris);
+                bool h = plain ? closest_hit<true, COUNT, true>(S, o, dirToLight, stk, best, nNodes, nTris)
+                               : closest_hit<true, COUNT, false>(S, o, dirToLight, stk, best, nNodes, nTris);
                 if (ltype == 0u) { v3 dl = best.loc - hitLoc; occ = h && (sqrtf(dot3(dl, dl)) < distToLight); }
                 else occ = h;
             } else {
-                occ = occluded_fast<COUNT>(S, o, dirToLight, (int)ltype, hitLoc, distToLight, stk, nNodes, nTris);
+                occ = plain ? occluded_fast<COUNT, true>(S, o, dirToLight, (int)ltype, hitLoc, distToLight, stk, nNodes, nTris)
+                            : occluded_fast<COUNT, false>(S, o, dirToLight, (int)ltype, hitLoc, distToLight, stk, nNodes, nTris);
             }
             *wp = occ ? 0.f : 2.f;
         }
