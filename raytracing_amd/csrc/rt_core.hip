@@ -207,10 +207,10 @@ PathBuffers make_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint
     return P;
 }
 
-template <typename... Args>
+template <bool PRIMARY, typename... Args>
 void launch_extend(bool exact, bool count, dim3 g, hipStream_t st, Args... a) {
-    if (exact) { if (count) k_extend<true, true><<<g, RT_BLOCK, 0, st>>>(a...); else k_extend<true, false><<<g, RT_BLOCK, 0, st>>>(a...); }
-    else { if (count) k_extend<false, true><<<g, RT_BLOCK, 0, st>>>(a...); else k_extend<false, false><<<g, RT_BLOCK, 0, st>>>(a...); }
+    if (exact) { if (count) k_extend<true, true, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...); else k_extend<true, false, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...); }
+    else { if (count) k_extend<false, true, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...); else k_extend<false, false, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...); }
 }
 template <typename... Args>
 void launch_shadow(bool exact, bool count, dim3 g, hipStream_t st, Args... a) {
@@ -320,13 +320,13 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         const uint32_t passBlocks = (Pp.nslots + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t tb = std::min(traceBlocks, passBlocks);
         HIPCHK(c, hipMemsetAsync(P.counters, 0, (size_t)(2 * (maxB + 1)) * 4, st));
-        k_raygen<<<passBlocks, RT_BLOCK, 0, st>>>(F, Pp, (int)rBase, qcount);
+        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)qcount, (int)Pp.nslots, 1, st));   // bounce 0: every slot carries a path
         for (uint32_t b = 0; b < maxB; b++) {
             uint32_t* qin = b == 0 ? nullptr : P.queues + (size_t)(b & 1) * nslots;   // bounce 0: identity queue
             uint32_t* qout = P.queues + (size_t)((b + 1) & 1) * nslots;
             rt_ctx::EvPair* e = evBegin(0);
-            launch_extend(exact, count, dim3(tb), st, S, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), b == 0 ? 1 : 0,
-                          b == 0 ? inPass * w * h : 0u, dst);
+            if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
+            else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
             evEnd(e);
             e = evBegin(1);
             k_shade<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), qout, qcount + b + 1,
@@ -554,8 +554,10 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     (void)hipMemsetAsync(dst, 0, sizeof(DeviceStats), st);
     uint32_t blocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
     k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, (const float*)dO.p, (const float*)dD.p, (uint32_t)n, P.queues, P.counters);
-    launch_extend(exact, count, dim3(trace_blocks(c, nslots)), st, S, P, (const uint32_t*)P.queues,
-                  (const uint32_t*)P.counters, 1, 0u, dst);
+    FrameParams F0;
+    std::memset(&F0, 0, sizeof F0);
+    launch_extend<false>(exact, count, dim3(trace_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues,
+                         (const uint32_t*)P.counters, 0, 0u, dst);
     hipError_t e = hipStreamSynchronize(st);
     std::vector<float> h4(n * 4);
     if (e == hipSuccess) e = hipMemcpy(h4.data(), P.hit, n * 16, hipMemcpyDeviceToHost);
@@ -569,7 +571,7 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
         if (hits) { hits[i * 3] = h4[i * 4]; hits[i * 3 + 1] = h4[i * 4 + 1]; hits[i * 3 + 2] = h4[i * 4 + 2]; }
     }
     std::memset(&c->stats, 0, sizeof c->stats);
-    c->stats.rays_primary = hs.rays_primary; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
+    c->stats.rays_primary = hs.rays_primary + hs.rays_bounce; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
     return RT_OK;
 }
 

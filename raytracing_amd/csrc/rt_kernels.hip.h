@@ -1,7 +1,7 @@
 // gfx950 wavefront path-tracing kernels (included by rt_core.hip).
 //
 // Pipeline per pass of S samples (S paths per pixel in flight; DESIGN.md "Wavefront pipeline"):
-//   k_raygen            shader.comp:309-324   ray generation for samples [rBase, rBase+S)
+//   (primary_ray)       shader.comp:309-324   camera rays of samples [rBase, rBase+S), regenerated from the slot index
 //   for bounce b:
 //     k_extend          shader.comp:243-290   closest hit (lineCast) over queue b
 //     k_shade           shader.comp:329-452,524-531  miss/ambient, surface fetch, dielectric/GGX bounce,
@@ -308,19 +308,17 @@ __device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// shader.comp:309-324 for sample r, one thread per slot of the region's 8x8-tiled slot space.  Bounce 0 needs no
-// queue: every slot carries a path (slots of edge tiles that fall outside the region are flagged dead).
+// shader.comp:309-324: the camera ray of slot `slot` (sample rBase + slot / slotsPerSample of its pixel).  Bounce 0
+// needs neither a queue nor stored rays: every slot carries a path and k_extend / k_shade regenerate the ray from
+// the slot index (a deterministic function, so both see identical bits).  Returns false for slots of edge tiles
+// that fall outside the region.
 #define RT_FLAG_REFRACTING 1u
-#define RT_FLAG_DEAD 2u
-__global__ __launch_bounds__(RT_BLOCK) void k_raygen(FrameParams F, PathBuffers P, int rBase, uint32_t* countOut) {
-    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (slot == 0) *countOut = P.nslots;
-    if (slot >= P.nslots) return;
+__device__ __forceinline__ bool primary_ray(const FrameParams& F, const PathBuffers& P, int rBase, uint32_t slot,
+                                            int* pxOut, int* pyOut, int* rOut, v3* dirOut) {
     int px, py;
     int r = rBase + (int)(slot / P.slotsPerSample);
     slot_to_pixel(F, slot % P.slotsPerSample, &px, &py);
-    P.depth[slot] = 0u;
-    bool valid = px < F.rx + F.rw && py < F.ry + F.rh;
+    *pxOut = px; *pyOut = py; *rOut = r;
     int N = F.gridN;
     int gx = r % N, gy = r / N;
     float jx = ((float)gx + 0.5f) / (float)N, jy = ((float)gy + 0.5f) / (float)N;
@@ -330,36 +328,42 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(FrameParams F, PathBuffers 
     float fx = ux * F.tanHalfFov;
     float fy = uy * F.tanHalfFov;
     v3 fwd = ld3(F.camForward), right = ld3(F.camRight), up = ld3(F.camUp);
-    v3 dir = (fwd + fx * right + fy * up);
-    P.rayO[slot] = make_float4(F.camPos[0], F.camPos[1], F.camPos[2], __uint_as_float(valid ? 0u : RT_FLAG_DEAD));
-    P.rayD[slot] = make_float4(dir.x, dir.y, dir.z, 0.f);
-    P.rayS[slot] = make_float4(F.initialStrength, F.initialStrength, F.initialStrength, 0.f);
+    *dirOut = (fwd + fx * right + fy * up);
+    return px < F.rx + F.rw && py < F.ry + F.rh;
 }
 
 // queue == nullptr: identity (bounce 0).  rayCount > 0 overrides the number of rays added to the counters
 // (bounce 0: region pixels, not slots).
-template <bool EXACT, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, PathBuffers P, const uint32_t* __restrict__ queue,
-                                                     const uint32_t* __restrict__ count, int isPrimary, uint32_t rayCount,
+template <bool EXACT, bool COUNT, bool PRIMARY>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ queue,
+                                                     const uint32_t* __restrict__ count, int rBase, uint32_t rayCount,
                                                      DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
     const Stack stk = make_stack(lds, P);
     uint32_t n = *count;
     uint32_t nNodes = 0, nTris = 0, maxSteps = 0;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
-        uint32_t slot = queue ? queue[i] : i;
-        float4 o4 = P.rayO[slot], d4 = P.rayD[slot];
-        if (__float_as_uint(o4.w) & RT_FLAG_DEAD) { P.hit[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-2)); continue; }
+        uint32_t slot;
+        v3 ro, rd;
+        if (PRIMARY) {
+            slot = i;
+            int px, py, r;
+            ro = ld3(F.camPos);
+            if (!primary_ray(F, P, rBase, slot, &px, &py, &r, &rd)) { P.hit[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-2)); continue; }
+        } else {
+            slot = queue[i];
+            float4 o4 = P.rayO[slot], d4 = P.rayD[slot];
+            ro = mk(o4.x, o4.y, o4.z); rd = mk(d4.x, d4.y, d4.z);
+        }
         HitRec best;
         uint32_t before = nNodes + nTris;
-        v3 ro = mk(o4.x, o4.y, o4.z), rd = mk(d4.x, d4.y, d4.z);
         if (__all(ray_is_plain(ro, rd))) closest_hit<EXACT, COUNT, true>(S, ro, rd, stk, best, nNodes, nTris);
         else closest_hit<EXACT, COUNT, false>(S, ro, rd, stk, best, nNodes, nTris);
         if (COUNT) { uint32_t steps = nNodes + nTris - before; if (steps > maxSteps) maxSteps = steps; }
         P.hit[slot] = make_float4(best.loc.x, best.loc.y, best.loc.z, __int_as_float(best.ref));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        atomicAdd(isPrimary ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)(rayCount ? rayCount : n));
+        atomicAdd(PRIMARY ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)(rayCount ? rayCount : n));
     if (COUNT) {
         __shared__ uint32_t red[2];
         if (threadIdx.x < 2) red[threadIdx.x] = 0;
@@ -447,16 +451,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
         uint32_t slot = 0;
         if (live) {
             slot = queue ? queue[i] : i;
-            float4 o4 = P.rayO[slot], d4 = P.rayD[slot], s4 = P.rayS[slot], h4 = P.hit[slot];
-            v3 rayLoc = mk(o4.x, o4.y, o4.z), rayDir = mk(d4.x, d4.y, d4.z), strength = mk(s4.x, s4.y, s4.z);
-            bool refracting = (__float_as_uint(o4.w) & RT_FLAG_REFRACTING) != 0u;
+            float4 h4 = P.hit[slot];
+            v3 rayLoc, rayDir, strength;
+            bool refracting = false;
+            int px, py, r;
+            if (bounce == 0) {
+                // camera ray regenerated from the slot index (see primary_ray)
+                primary_ray(F, P, rBase, slot, &px, &py, &r, &rayDir);
+                rayLoc = ld3(F.camPos);
+                strength = mk(F.initialStrength, F.initialStrength, F.initialStrength);
+            } else {
+                float4 o4 = P.rayO[slot], d4 = P.rayD[slot], s4 = P.rayS[slot];
+                rayLoc = mk(o4.x, o4.y, o4.z); rayDir = mk(d4.x, d4.y, d4.z); strength = mk(s4.x, s4.y, s4.z);
+                refracting = (__float_as_uint(o4.w) & RT_FLAG_REFRACTING) != 0u;
+                r = rBase + (int)(slot / P.slotsPerSample);
+                slot_to_pixel(F, slot % P.slotsPerSample, &px, &py);
+            }
             int ref = __float_as_int(h4.w);
-            int px, py;
-            const int r = rBase + (int)(slot / P.slotsPerSample);
-            slot_to_pixel(F, slot % P.slotsPerSample, &px, &py);
             v3 camPos = ld3(F.camPos);
             float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;   // entry of light l at logp[l * nslots]
-            if (ref != -2) P.depth[slot] = (uint32_t)bounce + 1u;
+            P.depth[slot] = ref == -2 ? 0u : (uint32_t)bounce + 1u;
             if (ref == -2) {
                 // dead slot (edge tile outside the region)
             } else if (ref < 0) {

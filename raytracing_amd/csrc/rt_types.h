@@ -96,8 +96,8 @@ struct TexDesc { const uint8_t* rgba8; uint32_t width, height; };
 
 #define RT_MAX_LIGHTS 8
 #define RT_MAX_STREAMS 8
-#define RT_LDS_STACK 16          // per-lane stack entries kept in LDS
-#define RT_SPILL_STACK 48        // further entries in scratch; total = 64 = shader.comp:246
+#define RT_LDS_STACK 8           // per-lane stack entries kept in LDS
+#define RT_SPILL_STACK 56        // further entries in scratch; total = 64 = shader.comp:246
 
 // Scene + frame constants handed to every kernel by value (kernarg segment -> SGPRs).
 struct SceneView {
