@@ -21,6 +21,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 MODELS = os.path.join(ROOT, "tests", "golden", "models")
 
+# BASELINE.json configs (SURVEY.md 8d gives the concrete inputs).  scene 0 = synthetic height field.
+WORKLOADS = {
+    "c1": dict(scene=3, width=512, height=512, spp=64, bounces=8, grid=0, desc="configs[0]: scene 3 (box + roughSphere, 330 tris, point light, textured)"),
+    "c2": dict(scene=4, width=1920, height=1080, spp=1024, bounces=8, grid=0, desc="configs[1]: scene 4 (scene4.gltf, 4802 tris, sun light)"),
+    "c3": dict(scene=7, width=1920, height=1080, spp=256, bounces=16, grid=0, desc="configs[2]: scene 7 (RayTracing.gltf, 44722 tris, rough glass, sun light; spp not given by BASELINE, 256 used)"),
+    "c4": dict(scene=0, width=1920, height=1080, spp=256, bounces=8, grid=3162, desc="configs[3]: synthetic height field, 2*grid^2 triangles, sun light"),
+}
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 S_NODE, S_TRI = 64, 48         # bytes per compact node / triangle record
 
@@ -30,18 +38,28 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    # workload = a BASELINE.json config; c2 is the headline (the default), the others are reported for context
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     # development overrides (a run with any of these set is labelled in config and is not the headline)
-    ap.add_argument("--scene", type=int, default=4)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--scene", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--bounces", type=int, default=None)
+    ap.add_argument("--grid", type=int, default=None, help="c4: quads per side of the synthetic height field (triangles = 2*grid^2)")
     ap.add_argument("--samples-per-pass", type=int, default=0, help="samplesPerPass override (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    args.overridden = any(getattr(args, k) is not None for k in ("scene", "width", "height", "spp", "bounces", "grid"))
+    for k in ("scene", "width", "height", "spp", "bounces", "grid"):
+        if getattr(args, k) is None:
+            setattr(args, k, wl[k])
+    args.desc = wl["desc"]
+    return args
 
 
 def cpu_baseline(args, gpu_image):
@@ -51,7 +69,14 @@ def cpu_baseline(args, gpu_image):
     ref.build()
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    sc = ref.load_scene(MODELS, args.scene)
+    if args.scene == 0:
+        from oracle import gltf_flatten as G
+        from raytracing_amd import synthetic
+        flat = G.flatten([args.synthetic_path + ".gltf"])
+        flat["lights"], flat["hasSun"] = G.lights_to_gpu(synthetic.SYNTHETIC_LIGHTS)
+        sc = ref.Scene(flat)
+    else:
+        sc = ref.load_scene(MODELS, args.scene)
     W, H = args.width, args.height
 
     def run(s):
@@ -88,7 +113,15 @@ def main():
     from raytracing_amd.distributed import image_tensor, sample_range
 
     cs = ComputeShader(device=dev, rank=rank, world_size=world)
-    S.Scene.LoadScene(cs, args.scene, MODELS)
+    if args.scene == 0:
+        import tempfile
+        from raytracing_amd import synthetic
+        args.synthetic_path = os.path.join(tempfile.gettempdir(), "rt_synth_%d_rank%d" % (args.grid, rank))
+        ntri, nvert = synthetic.write_gltf(args.synthetic_path, args.grid)
+        S.Scene.LoadModels(cs, [args.synthetic_path + ".gltf"], synthetic.SYNTHETIC_LIGHTS)
+        args.desc += " (%d triangles, %d vertices)" % (ntri, nvert)
+    else:
+        S.Scene.LoadScene(cs, args.scene, MODELS)
     load_t = S.Scene.timings()
     W, H = args.width, args.height
     cs.resize(W, H)
@@ -160,22 +193,22 @@ def main():
                     "tris_per_ray": round(c["tri_tests"] / max(1, ext_rays_c), 2),
                     "shadow_alg_bytes_per_ray": round(sh_bytes_per_ray, 1),
                     "kernel_ms_per_step": {k: round(agg[k] / args.steps, 2) for k in ("ms_extend", "ms_shade", "ms_shadow")},
-                    "note": "scene is cache-resident (<1 MB): the binding limit is the CU vector-memory/VALU path, "
-                            "HBM fraction is the contract's sanity figure (BASELINE.md)"}
+                    "note": "bundled scenes are cache-resident (<= 13 MB): there the binding limit is the CU vector-memory/VALU path and "
+                            "the HBM fraction is the contract's sanity figure (BASELINE.md); c4 is the HBM-bound configuration"}
         cpu = None
         if not args.no_cpu_baseline:
             try:
                 cpu = cpu_baseline(args, None)
             except Exception as e:  # the baseline is reporting only; never fail the bench on it
                 cpu = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        headline = (args.scene == 4 and W == 1920 and H == 1080 and args.spp == 1024 and args.bounces == 8)
+        headline = (args.workload == "c2" and not args.overridden)
         out = {
             "metric": "Mrays/s at 1080p 8-bounce", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "bundled scene (tests/golden/models), default camera",
-            "config": {"workload": "configs[1]: scene 4 (scene4.gltf, 4802 tris, sun light) %dx%d, %d spp, %d bounces%s"
-                                   % (W, H, args.spp, args.bounces, "" if headline else " [NON-HEADLINE override]"),
+            "config": {"workload": "%s %dx%d, %d spp, %d bounces%s"
+                                   % (args.desc, W, H, args.spp, args.bounces, "" if headline else " [NOT THE HEADLINE CONFIG]"),
                        "parallelism": "sample-range x%d, RCCL reduce of the colour buffer" % world if world > 1 else "single GPU",
                        "traversal": "culled/ordered (traversalMode 0)"},
             "rays": {"total": rays, "primary": agg["rays_primary"], "bounce": agg["rays_bounce"], "shadow": agg["rays_shadow"],

@@ -280,7 +280,11 @@ __device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, in
             float t0, t1;
             bool p0 = slab<FAST>(o, inv, lo0, hi0, &t0) && !(t0 > lim);
             bool p1 = slab<FAST>(o, inv, lo1, hi1, &t1) && !(t1 > lim);
-            if (p0 && p1) { uint2 e; e.x = (uint32_t)c1; e.y = 0u; stk.push(sp, e); cur = c0; }
+            if (p0 && p1) {      // nearer box first: an occluder, if any, tends to be found sooner
+                bool swap = t1 < t0;
+                uint2 e; e.x = (uint32_t)(swap ? c0 : c1); e.y = 0u; stk.push(sp, e);
+                cur = swap ? c1 : c0;
+            }
             else if (p0) cur = c0;
             else if (p1) cur = c1;
             else if (sp > 0) cur = (int)stk.pop(sp).x;
