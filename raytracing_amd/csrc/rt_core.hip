@@ -41,7 +41,7 @@ struct rt_ctx {
     float camPos[3] = {0, 0, 0}, camForward[3] = {0, 0, -1}, camRight[3] = {1, 0, 0}, camUp[3] = {0, 1, 0};
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
-    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 32, blocksPerCU = 8;
+    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 128;
 
     // device scene
     DevBuf dNodes, dTris, dShade, dMaterials, dVertices, dLights, dTexDescs;
