@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--grid", type=int, default=None, help="c4: quads per side of the synthetic height field (triangles = 2*grid^2)")
     ap.add_argument("--samples-per-pass", type=int, default=0, help="samplesPerPass override (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -101,10 +103,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    if args.share_gpu:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     dev = local if world > 1 else 0
     torch.cuda.set_device(dev)
 
