@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="extra rt_set_int tuning knobs (refillIdle, dynamicFetch, dynBlocksPerCU ...)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -138,6 +139,9 @@ def main():
         cs.setInt("samplesPerPass", args.samples_per_pass)
     if args.blocks_per_cu:
         cs.setInt("blocksPerCU", args.blocks_per_cu)
+    for kv in args.set:
+        k, v = kv.split("=")
+        cs.setInt(k, int(v))
     S.set_camera(cs, S.DEFAULT_CAMERA[0], S.DEFAULT_CAMERA[1], W, H, 45.0)
     r0, r1 = sample_range(args.spp, rank, world)
     color = image_tensor(cs, 0)

@@ -155,21 +155,26 @@ __device__ __forceinline__ void test_tri(float4 A, float4 B, float4 C, int idx, 
 // from the tree depth at scene load (coalesced the same way).  No scratch memory is used.  A push beyond the
 // total capacity (>= 64 entries = shader.comp:246) is dropped like the reference's `stackPtr < 64` guard.
 struct Stack {
-    uint2* lds; uint2* ov; uint32_t ovStride; int cap;
+    uint2* lds; volatile uint32_t* ov; uint32_t ovStride; int cap;
+    // The overflow accesses are volatile so that the compiler keeps them apart from the LDS accesses (merged, both
+    // become flat_* instructions on a selected pointer, which are slower than ds_* and count on two wait counters).
     __device__ __forceinline__ void push(int& sp, uint2 e) const {
         if (sp < RT_LDS_STACK) lds[sp * RT_BLOCK] = e;
-        else if (sp < cap) ov[(size_t)(sp - RT_LDS_STACK) * ovStride] = e;
+        else if (sp < cap) { volatile uint32_t* q = ov + (size_t)(sp - RT_LDS_STACK) * ovStride * 2u; q[0] = e.x; q[1] = e.y; }
         if (sp < cap) sp++;
     }
     __device__ __forceinline__ uint2 pop(int& sp) const {
         sp--;
-        return (sp < RT_LDS_STACK) ? lds[sp * RT_BLOCK] : ov[(size_t)(sp - RT_LDS_STACK) * ovStride];
+        if (sp < RT_LDS_STACK) return lds[sp * RT_BLOCK];
+        volatile uint32_t* q = ov + (size_t)(sp - RT_LDS_STACK) * ovStride * 2u;
+        uint2 e; e.x = q[0]; e.y = q[1];
+        return e;
     }
 };
 __device__ __forceinline__ Stack make_stack(uint2* ldsBase, const struct PathBuffers& P) {
     Stack st;
     st.lds = ldsBase + threadIdx.x;
-    st.ov = P.overflow + (blockIdx.x * RT_BLOCK + threadIdx.x);
+    st.ov = reinterpret_cast<volatile uint32_t*>(P.overflow + (blockIdx.x * RT_BLOCK + threadIdx.x));
     st.ovStride = P.overflowStride;
     st.cap = RT_LDS_STACK + (int)P.overflowDepth;
     return st;
@@ -800,3 +805,5 @@ __global__ __launch_bounds__(RT_BLOCK) void k_load_rays(PathBuffers P, const flo
 }
 
 }  // namespace rt
+
+#include "rt_trace_dyn.hip.h"
