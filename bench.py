@@ -203,6 +203,9 @@ def main():
                     "nodes_per_ray": round(c["node_visits"] / max(1, ext_rays_c), 2),
                     "tris_per_ray": round(c["tri_tests"] / max(1, ext_rays_c), 2),
                     "shadow_alg_bytes_per_ray": round(sh_bytes_per_ray, 1),
+                    "bounce_lane_utilisation": {"node_step": round(c["bounce_node_visits"] / max(1, 64 * c["wave_node_steps"]), 3),
+                                                "tri_step": round(c["bounce_tri_tests"] / max(1, 64 * c["wave_tri_steps"]), 3),
+                                                "wave_node_steps": c["wave_node_steps"], "wave_tri_steps": c["wave_tri_steps"]},
                     "kernel_ms_per_step": {k: round(agg[k] / args.steps, 2) for k in ("ms_extend", "ms_shade", "ms_shadow")},
                     "note": "bundled scenes are cache-resident (<= 13 MB): there the binding limit is the CU vector-memory/VALU path and "
                             "the HBM fraction is the contract's sanity figure (BASELINE.md); c4 is the HBM-bound configuration"}

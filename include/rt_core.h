@@ -127,6 +127,10 @@ typedef struct rt_stats {
     uint64_t launches_extend;  /* kernel launches behind ms_extend                             */
     uint64_t launches_shade;
     uint64_t launches_shadow;
+    uint64_t bounce_node_visits; /* node_visits / tri_tests of bounces >= 1 only (countVisits = 1)            */
+    uint64_t bounce_tri_tests;
+    uint64_t wave_node_steps;  /* wave-level executions of the node step / triangle step by those kernels:   */
+    uint64_t wave_tri_steps;   /* lane utilisation of a step = visits / (64 x executions)                     */
 } rt_stats;
 rt_status rt_get_stats(rt_ctx* ctx, rt_stats* out);
 

@@ -21,7 +21,9 @@ class RtStats(C.Structure):
                 ("rays_shadow_skipped", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64), ("max_ray_steps", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
-                ("launches_extend", C.c_uint64), ("launches_shade", C.c_uint64), ("launches_shadow", C.c_uint64)]
+                ("launches_extend", C.c_uint64), ("launches_shade", C.c_uint64), ("launches_shadow", C.c_uint64),
+                ("bounce_node_visits", C.c_uint64), ("bounce_tri_tests", C.c_uint64),
+                ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

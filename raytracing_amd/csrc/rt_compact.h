@@ -188,6 +188,31 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
             (which ? out.nodes[cidx].child1 : out.nodes[cidx].child0) = nidx;
         }
     }
+
+    // Renumber the internal nodes breadth-first: any prefix of the array is then the top of the tree, which the
+    // traversal kernels keep resident in LDS (rt_trace_dyn.hip.h).  Triangle order (= visit rank) is untouched.
+    {
+        const size_t n = out.nodes.size();
+        std::vector<int32_t> order; order.reserve(n);          // order[new] = old
+        std::vector<int32_t> newIdx(n, -1);
+        order.push_back(out.rootChild);
+        for (size_t head = 0; head < order.size(); head++) {
+            const CNode& nd = out.nodes[(size_t)order[head]];
+            newIdx[(size_t)order[head]] = (int32_t)head;
+            if (nd.child0 >= 0) order.push_back(nd.child0);
+            if (nd.child1 >= 0) order.push_back(nd.child1);
+        }
+        if (order.size() != n) return "internal error: BVH renumbering lost nodes";
+        std::vector<CNode> re(n);
+        for (size_t i = 0; i < n; i++) {
+            CNode nd = out.nodes[(size_t)order[i]];
+            if (nd.child0 >= 0) nd.child0 = newIdx[(size_t)nd.child0];
+            if (nd.child1 >= 0) nd.child1 = newIdx[(size_t)nd.child1];
+            re[i] = nd;
+        }
+        out.nodes.swap(re);
+        out.rootChild = 0;
+    }
     return "";
 }
 

@@ -42,7 +42,7 @@ struct rt_ctx {
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
     int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 128;
-    int32_t dynamicFetch = 1, refillIdle = 24, dynBlocksPerCU = 32, poolChunk = 1024;
+    int32_t dynamicFetch = 1, refillIdle = 24;
 
     // device scene
     DevBuf dNodes, dTris, dShade, dMaterials, dVertices, dLights, dTexDescs;
@@ -157,6 +157,7 @@ SceneView make_view(rt_ctx* c, bool exact) {
     S.materials = (const RefMaterial*)c->dMaterials.p; S.vertices = (const RefVertex*)c->dVertices.p;
     S.lights = (const RefLight*)c->dLights.p; S.textures = (const TexDesc*)c->dTexDescs.p;
     S.n_textures = (uint32_t)c->textures.size();
+    S.n_nodes = (uint32_t)c->cs.nodes.size();
     S.rootChild = c->cs.rootChild;
     for (int k = 0; k < 3; k++) { S.rootLo[k] = c->cs.rootLo[k]; S.rootHi[k] = c->cs.rootHi[k]; }
     S.cullAbs = 1e-5f * c->cs.sceneScale;
@@ -173,19 +174,19 @@ uint32_t trace_blocks(rt_ctx* c, uint32_t nslots) {
     return slotBlocks < persistent ? slotBlocks : persistent;
 }
 // persistent grid of the dynamic-fetch traversal kernels (rt_trace_dyn.hip.h): what is resident at once
+// (one 1024-thread workgroup per CU: each holds the BVH top in its CU's LDS)
 uint32_t dyn_blocks(rt_ctx* c, uint32_t nItems) {
-    uint32_t itemBlocks = (nItems + RT_BLOCK - 1) / RT_BLOCK;
-    uint32_t persistent = (uint32_t)c->numCUs * (uint32_t)c->dynBlocksPerCU;
+    uint32_t itemBlocks = (nItems + RT_DYN_BLOCK - 1) / RT_DYN_BLOCK;
+    uint32_t persistent = (uint32_t)c->numCUs;
     return std::max(1u, itemBlocks < persistent ? itemBlocks : persistent);
 }
-int refill_arg(rt_ctx* c) {
-    int idle = std::min(64, std::max(1, (int)c->refillIdle));
-    int chunk = std::min(1 << 20, std::max(64, (int)c->poolChunk)) & ~63;
-    return idle | (chunk << 8);
+uint32_t stack_threads(rt_ctx* c, uint32_t nslots) {
+    return std::max(trace_blocks(c, nslots) * RT_BLOCK, dyn_blocks(c, nslots) * RT_DYN_BLOCK);
 }
+int refill_arg(rt_ctx* c) { return std::min(64, std::max(1, (int)c->refillIdle)); }
 uint32_t overflow_depth(rt_ctx* c) {
     // ordered traversal keeps at most one pending sibling per level: depth <= tree depth
-    int need = (int)c->cs.maxDepth + 1 - RT_LDS_STACK;
+    int need = (int)c->cs.maxDepth + 1 - std::min(RT_LDS_STACK, RT_DYN_STACK);
     if (need < 0) need = 0;
     if (need > RT_SPILL_STACK) need = RT_SPILL_STACK;
     return (uint32_t)need;
@@ -194,7 +195,7 @@ uint32_t overflow_depth(rt_ctx* c) {
 rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
     rt_status s;
     size_t n = nslots;
-    if ((s = ensure(c, c->overflow, (size_t)overflow_depth(c) * std::max(trace_blocks(c, nslots), dyn_blocks(c, nslots)) * RT_BLOCK * sizeof(uint2)))) return s;
+    if ((s = ensure(c, c->overflow, (size_t)overflow_depth(c) * stack_threads(c, nslots) * sizeof(uint2)))) return s;
     if ((s = ensure(c, c->rayO, n * 16))) return s;
     if ((s = ensure(c, c->rayD, n * 16))) return s;
     if ((s = ensure(c, c->rayS, n * 16))) return s;
@@ -204,7 +205,7 @@ rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint
     if ((s = ensure(c, c->accum, (size_t)slotsPerSample * 16))) return s;
     if ((s = ensure(c, c->queues, n * 4 * 2))) return s;
     if ((s = ensure(c, c->shadowQueue, n * 4))) return s;
-    if ((s = ensure(c, c->counters, (size_t)(4 * (maxBounces + 1)) * 4))) return s;   // queue sizes, shadow-queue sizes, 2 x work-pool cursors
+    if ((s = ensure(c, c->counters, (size_t)(2 * (maxBounces + 1)) * 4))) return s;
     if ((s = ensure(c, c->dStats, sizeof(DeviceStats)))) return s;
     return RT_OK;
 }
@@ -215,7 +216,7 @@ PathBuffers make_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint
     P.contrib = (float4*)c->contrib.p; P.depth = (uint32_t*)c->depth.p; P.accum = (float4*)c->accum.p;
     P.queues = (uint32_t*)c->queues.p; P.shadowQueue = (uint32_t*)c->shadowQueue.p; P.counters = (uint32_t*)c->counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots;
-    P.overflow = (uint2*)c->overflow.p; P.overflowStride = std::max(trace_blocks(c, nslots), dyn_blocks(c, nslots)) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
+    P.overflow = (uint2*)c->overflow.p; P.overflowStride = stack_threads(c, nslots); P.overflowDepth = overflow_depth(c);
     return P;
 }
 
@@ -226,7 +227,7 @@ void launch_extend(bool exact, bool count, dim3 g, hipStream_t st, Args... a) {
 }
 template <bool PRIMARY, typename... Args>
 void launch_extend_dyn(bool count, dim3 g, hipStream_t st, Args... a) {
-    if (count) k_extend_dyn<true, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...); else k_extend_dyn<false, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...);
+    if (count) k_extend_dyn<true, PRIMARY><<<g, RT_DYN_BLOCK, 0, st>>>(a...); else k_extend_dyn<false, PRIMARY><<<g, RT_DYN_BLOCK, 0, st>>>(a...);
 }
 template <typename... Args>
 void launch_shadow(bool exact, bool count, dim3 g, hipStream_t st, Args... a) {
@@ -302,8 +303,6 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
     uint32_t* qcount = P.counters;
     uint32_t* scount = P.counters + (maxB + 1);
-    uint32_t* wExt = P.counters + 2 * (maxB + 1);      // work-pool cursors of the dynamic-fetch kernels
-    uint32_t* wSh = P.counters + 3 * (maxB + 1);
     const bool dyn = !exact && c->dynamicFetch != 0;
     const int refill = refill_arg(c);
     // Optional per-kernel-class timing with HIP events on the launch stream (ring of pairs, drained lazily).
@@ -339,7 +338,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         Pp.nslots = inPass * sps;                  // a short last pass uses its own (smaller) log strides
         const uint32_t passBlocks = (Pp.nslots + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t tb = std::min(traceBlocks, passBlocks);
-        HIPCHK(c, hipMemsetAsync(P.counters, 0, (size_t)(4 * (maxB + 1)) * 4, st));
+        HIPCHK(c, hipMemsetAsync(P.counters, 0, (size_t)(2 * (maxB + 1)) * 4, st));
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)qcount, (int)Pp.nslots, 1, st));   // bounce 0: every slot carries a path
         for (uint32_t b = 0; b < maxB; b++) {
             uint32_t* qin = b == 0 ? nullptr : P.queues + (size_t)(b & 1) * nslots;   // bounce 0: identity queue
@@ -347,8 +346,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             rt_ctx::EvPair* e = evBegin(0);
             if (dyn) {
                 const dim3 dg(dyn_blocks(c, Pp.nslots));
-                if (b == 0) launch_extend_dyn<true>(count, dg, st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, wExt + b, (int)rBase, inPass * w * h, refill, dst);
-                else launch_extend_dyn<false>(count, dg, st, S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), wExt + b, (int)rBase, 0u, refill, dst);
+                if (b == 0) launch_extend_dyn<true>(count, dg, st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, refill, dst);
+                else launch_extend_dyn<false>(count, dg, st, S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refill, dst);
             }
             else if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
             else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
@@ -361,8 +360,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                 e = evBegin(2);
                 if (dyn) {
                     const dim3 dg(dyn_blocks(c, Pp.nslots));
-                    if (count) k_shadow_dyn<true><<<dg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), wSh + b, (int)b, refill, dst);
-                    else k_shadow_dyn<false><<<dg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), wSh + b, (int)b, refill, dst);
+                    if (count) k_shadow_dyn<true><<<dg, RT_DYN_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refill, dst);
+                    else k_shadow_dyn<false><<<dg, RT_DYN_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refill, dst);
                 }
                 else launch_shadow(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
                 evEnd(e);
@@ -384,6 +383,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.ms_total = std::chrono::duration<double, std::milli>(t1 - t0).count();
     c->stats.shadow_node_visits = hs.shadow_node_visits; c->stats.shadow_tri_tests = hs.shadow_tri_tests;
     c->stats.max_ray_steps = hs.max_ray_steps;
+    c->stats.bounce_node_visits = hs.bounce_node_visits; c->stats.bounce_tri_tests = hs.bounce_tri_tests;
+    c->stats.wave_node_steps = hs.wave_node_steps; c->stats.wave_tri_steps = hs.wave_tri_steps;
     c->stats.ms_extend = msAcc[0]; c->stats.ms_shade = msAcc[1]; c->stats.ms_shadow = msAcc[2];
     c->stats.launches_extend = nLaunch[0]; c->stats.launches_shade = nLaunch[1]; c->stats.launches_shadow = nLaunch[2];
     c->primValid = aov;
@@ -456,8 +457,6 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
     else if (name_is(name, "dynamicFetch")) c->dynamicFetch = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
-    else if (name_is(name, "poolChunk")) c->poolChunk = v;
-    else if (name_is(name, "dynBlocksPerCU")) c->dynBlocksPerCU = v < 1 ? 1 : v;
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
 }
 rt_status rt_set_float(rt_ctx* c, const char* name, float v) {
@@ -587,13 +586,12 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     DeviceStats* dst = (DeviceStats*)c->dStats.p;
     (void)hipMemsetAsync(dst, 0, sizeof(DeviceStats), st);
     uint32_t blocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
-    (void)hipMemsetAsync(P.counters, 0, 8 * 4, st);
     k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, (const float*)dO.p, (const float*)dD.p, (uint32_t)n, P.queues, P.counters);
     FrameParams F0;
     std::memset(&F0, 0, sizeof F0);
     if (!exact && c->dynamicFetch != 0)
         launch_extend_dyn<false>(count, dim3(dyn_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues, (const uint32_t*)P.counters,
-                                 P.counters + 4, 0, 0u, refill_arg(c), dst);
+                                 0, 0u, refill_arg(c), dst);
     else
         launch_extend<false>(exact, count, dim3(trace_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues,
                              (const uint32_t*)P.counters, 0, 0u, dst);

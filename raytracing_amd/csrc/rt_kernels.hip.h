@@ -156,27 +156,31 @@ __device__ __forceinline__ void test_tri(float4 A, float4 B, float4 C, int idx, 
 // total capacity (>= 64 entries = shader.comp:246) is dropped like the reference's `stackPtr < 64` guard.
 struct Stack {
     uint2* lds; volatile uint32_t* ov; uint32_t ovStride; int cap;
+    int ldsDepth, ldsStride;   // entries kept in LDS per lane, distance between a lane's consecutive entries (= workgroup size)
     // The overflow accesses are volatile so that the compiler keeps them apart from the LDS accesses (merged, both
     // become flat_* instructions on a selected pointer, which are slower than ds_* and count on two wait counters).
     __device__ __forceinline__ void push(int& sp, uint2 e) const {
-        if (sp < RT_LDS_STACK) lds[sp * RT_BLOCK] = e;
-        else if (sp < cap) { volatile uint32_t* q = ov + (size_t)(sp - RT_LDS_STACK) * ovStride * 2u; q[0] = e.x; q[1] = e.y; }
+        if (sp < ldsDepth) lds[sp * ldsStride] = e;
+        else if (sp < cap) { volatile uint32_t* q = ov + (size_t)(sp - ldsDepth) * ovStride * 2u; q[0] = e.x; q[1] = e.y; }
         if (sp < cap) sp++;
     }
     __device__ __forceinline__ uint2 pop(int& sp) const {
         sp--;
-        if (sp < RT_LDS_STACK) return lds[sp * RT_BLOCK];
-        volatile uint32_t* q = ov + (size_t)(sp - RT_LDS_STACK) * ovStride * 2u;
+        if (sp < ldsDepth) return lds[sp * ldsStride];
+        volatile uint32_t* q = ov + (size_t)(sp - ldsDepth) * ovStride * 2u;
         uint2 e; e.x = q[0]; e.y = q[1];
         return e;
     }
 };
-__device__ __forceinline__ Stack make_stack(uint2* ldsBase, const struct PathBuffers& P) {
+// ldsBase: ldsDepth x block entries (block = workgroup size).  The overflow area holds P.overflowDepth entries per thread of the grid
+// beyond the ldsDepth LDS ones (sized on the host for the smallest ldsDepth any kernel uses).
+__device__ __forceinline__ Stack make_stack(uint2* ldsBase, const struct PathBuffers& P, int ldsDepth = RT_LDS_STACK, int block = RT_BLOCK) {
     Stack st;
     st.lds = ldsBase + threadIdx.x;
-    st.ov = reinterpret_cast<volatile uint32_t*>(P.overflow + (blockIdx.x * RT_BLOCK + threadIdx.x));
+    st.ldsDepth = ldsDepth; st.ldsStride = block;
+    st.ov = reinterpret_cast<volatile uint32_t*>(P.overflow + (blockIdx.x * (uint32_t)block + threadIdx.x));
     st.ovStride = P.overflowStride;
-    st.cap = RT_LDS_STACK + (int)P.overflowDepth;
+    st.cap = ldsDepth + (int)P.overflowDepth;
     return st;
 }
 
@@ -187,9 +191,16 @@ __device__ __forceinline__ Stack make_stack(uint2* ldsBase, const struct PathBuf
 // of both bodies per step.
 //   EXACT:  reference order (right child first), no culling, leaf children always entered.
 //   !EXACT: near child first, distance culling with slack, padded leaf boxes.  Same winner: DESIGN.md.
+__device__ __forceinline__ bool first_active_lane() {
+    unsigned long long m = __ballot(true);
+    return (m & ((1ull << (threadIdx.x & 63u)) - 1ull)) == 0ull;
+}
+
+// wSteps (COUNT only, may be null): [0] += wave-level executions of the node step, [1] += of the triangle step,
+// counted by the first active lane of each execution (lane utilisation = visits / (64 x executions)).
 template <bool EXACT, bool COUNT, bool FAST>
 __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, const Stack& stk, HitRec& best,
-                                            uint32_t& nNodes, uint32_t& nTris) {
+                                            uint32_t& nNodes, uint32_t& nTris, uint32_t* wSteps = nullptr) {
     best.dist = 3.40282347e+38f; best.t = __int_as_float(0x7f800000); best.idx = -1; best.ref = -1;
     best.loc = mk(0.f, 0.f, 0.f);
     v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -214,7 +225,7 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, cons
         while (cur >= 0) {
             const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
             float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-            if (COUNT) nNodes++;
+            if (COUNT) { nNodes++; if (wSteps && first_active_lane()) wSteps[0]++; }
             float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
             float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
             int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
@@ -249,7 +260,7 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, cons
             int first = code >> 3, cnt = code & 7;
             const float4* tp = reinterpret_cast<const float4*>(S.tris + first);
             for (int k = 0; k < cnt; k++) {
-                if (COUNT) nTris++;
+                if (COUNT) { nTris++; if (wSteps && first_active_lane()) wSteps[1]++; }
                 test_tri<EXACT>(tp[3 * k], tp[3 * k + 1], tp[3 * k + 2], first + k, o, d, best);
             }
             popNext();
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F,
     const Stack stk = make_stack(lds, P);
     uint32_t n = *count;
     uint32_t nNodes = 0, nTris = 0, maxSteps = 0;
+    uint32_t wSteps[2] = {0u, 0u};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         uint32_t slot;
         v3 ro, rd;
@@ -366,24 +378,36 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F,
         }
         HitRec best;
         uint32_t before = nNodes + nTris;
-        if (__all(ray_is_plain(ro, rd))) closest_hit<EXACT, COUNT, true>(S, ro, rd, stk, best, nNodes, nTris);
-        else closest_hit<EXACT, COUNT, false>(S, ro, rd, stk, best, nNodes, nTris);
+        if (__all(ray_is_plain(ro, rd))) closest_hit<EXACT, COUNT, true>(S, ro, rd, stk, best, nNodes, nTris, wSteps);
+        else closest_hit<EXACT, COUNT, false>(S, ro, rd, stk, best, nNodes, nTris, wSteps);
         if (COUNT) { uint32_t steps = nNodes + nTris - before; if (steps > maxSteps) maxSteps = steps; }
         P.hit[slot] = make_float4(best.loc.x, best.loc.y, best.loc.z, __int_as_float(best.ref));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(PRIMARY ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)(rayCount ? rayCount : n));
     if (COUNT) {
-        __shared__ uint32_t red[2];
-        if (threadIdx.x < 2) red[threadIdx.x] = 0;
+        __shared__ uint32_t red[4];
+        if (threadIdx.x < 4) red[threadIdx.x] = 0;
         __syncthreads();
-        for (int off = 32; off > 0; off >>= 1) { nNodes += __shfl_down(nNodes, off, 64); nTris += __shfl_down(nTris, off, 64); }
+        for (int off = 32; off > 0; off >>= 1) {
+            nNodes += __shfl_down(nNodes, off, 64); nTris += __shfl_down(nTris, off, 64);
+            wSteps[0] += __shfl_down(wSteps[0], off, 64); wSteps[1] += __shfl_down(wSteps[1], off, 64);
+        }
         for (int off = 32; off > 0; off >>= 1) { uint32_t o2 = __shfl_down(maxSteps, off, 64); if (o2 > maxSteps) maxSteps = o2; }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nNodes); atomicAdd(&red[1], nTris); if (maxSteps) atomicMax(&stats->max_ray_steps, (unsigned long long)maxSteps); }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&red[0], nNodes); atomicAdd(&red[1], nTris); atomicAdd(&red[2], wSteps[0]); atomicAdd(&red[3], wSteps[1]);
+            if (maxSteps) atomicMax(&stats->max_ray_steps, (unsigned long long)maxSteps);
+        }
         __syncthreads();
         if (threadIdx.x == 0 && (red[0] | red[1])) {
             atomicAdd(&stats->node_visits, (unsigned long long)red[0]);
             atomicAdd(&stats->tri_tests, (unsigned long long)red[1]);
+            if (!PRIMARY) {
+                atomicAdd(&stats->bounce_node_visits, (unsigned long long)red[0]);
+                atomicAdd(&stats->bounce_tri_tests, (unsigned long long)red[1]);
+                atomicAdd(&stats->wave_node_steps, (unsigned long long)red[2]);
+                atomicAdd(&stats->wave_tri_steps, (unsigned long long)red[3]);
+            }
         }
     }
 }

@@ -109,6 +109,7 @@ struct SceneView {
     const RefLight* lights;
     const TexDesc* textures;
     uint32_t n_textures;
+    uint32_t n_nodes;              // CNode records (breadth-first order)
     int32_t rootChild;             // >= 0 internal CNode index, < 0 leaf code (root is a leaf)
     float rootLo[3], rootHi[3];    // reference box of node 0 (tested first, shader.comp:249-256)
     float cullAbs;                 // absolute slack of the distance cull (traversalMode 0)
@@ -132,6 +133,8 @@ struct DeviceStats {
     unsigned long long node_visits, tri_tests;                 // closest-hit (k_extend) traversal
     unsigned long long shadow_node_visits, shadow_tri_tests;   // shadow (k_shadow) traversal
     unsigned long long max_ray_steps;                          // most node visits + triangle tests by one closest-hit ray
+    unsigned long long bounce_node_visits, bounce_tri_tests;   // closest-hit traversal of bounces >= 1 only
+    unsigned long long wave_node_steps, wave_tri_steps;        // wave-level executions of the node / triangle step there
 };
 
 }  // namespace rt

@@ -17,9 +17,11 @@ PASSES=(
  "TA_TA_BUSY_sum TA_BUSY_avr GRBM_TA_BUSY"
  "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_VMEM_TA_ADDR_FIFO_FULL"
 )
+# PMC_ONLY="1 2": run only these passes
 i=0
 for p in "${PASSES[@]}"; do
   i=$((i+1))
+  if [ -n "${PMC_ONLY:-}" ] && ! [[ " $PMC_ONLY " == *" $i "* ]]; then continue; fi
   timeout -s KILL 240 rocprofv3 --pmc $p --output-format csv -d "$OUT/pass$i" -- python "$ROOT/bench.py" "$@" > "$OUT/pass$i.log" 2>&1
   rc=$?
   echo "pass $i ($p) rc=$rc"
