@@ -42,7 +42,6 @@ struct rt_ctx {
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
     int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 128;
-    int32_t dynamicFetch = 1, refillIdle = 24;
 
     // device scene
     DevBuf dNodes, dTris, dShade, dMaterials, dVertices, dLights, dTexDescs;
@@ -157,7 +156,6 @@ SceneView make_view(rt_ctx* c, bool exact) {
     S.materials = (const RefMaterial*)c->dMaterials.p; S.vertices = (const RefVertex*)c->dVertices.p;
     S.lights = (const RefLight*)c->dLights.p; S.textures = (const TexDesc*)c->dTexDescs.p;
     S.n_textures = (uint32_t)c->textures.size();
-    S.n_nodes = (uint32_t)c->cs.nodes.size();
     S.rootChild = c->cs.rootChild;
     for (int k = 0; k < 3; k++) { S.rootLo[k] = c->cs.rootLo[k]; S.rootHi[k] = c->cs.rootHi[k]; }
     S.cullAbs = 1e-5f * c->cs.sceneScale;
@@ -173,20 +171,9 @@ uint32_t trace_blocks(rt_ctx* c, uint32_t nslots) {
     uint32_t persistent = (uint32_t)c->numCUs * (uint32_t)c->blocksPerCU;
     return slotBlocks < persistent ? slotBlocks : persistent;
 }
-// persistent grid of the dynamic-fetch traversal kernels (rt_trace_dyn.hip.h): what is resident at once
-// (one 1024-thread workgroup per CU: each holds the BVH top in its CU's LDS)
-uint32_t dyn_blocks(rt_ctx* c, uint32_t nItems) {
-    uint32_t itemBlocks = (nItems + RT_DYN_BLOCK - 1) / RT_DYN_BLOCK;
-    uint32_t persistent = (uint32_t)c->numCUs;
-    return std::max(1u, itemBlocks < persistent ? itemBlocks : persistent);
-}
-uint32_t stack_threads(rt_ctx* c, uint32_t nslots) {
-    return std::max(trace_blocks(c, nslots) * RT_BLOCK, dyn_blocks(c, nslots) * RT_DYN_BLOCK);
-}
-int refill_arg(rt_ctx* c) { return std::min(64, std::max(1, (int)c->refillIdle)); }
 uint32_t overflow_depth(rt_ctx* c) {
     // ordered traversal keeps at most one pending sibling per level: depth <= tree depth
-    int need = (int)c->cs.maxDepth + 1 - std::min(RT_LDS_STACK, RT_DYN_STACK);
+    int need = (int)c->cs.maxDepth + 1 - RT_LDS_STACK;
     if (need < 0) need = 0;
     if (need > RT_SPILL_STACK) need = RT_SPILL_STACK;
     return (uint32_t)need;
@@ -195,7 +182,7 @@ uint32_t overflow_depth(rt_ctx* c) {
 rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
     rt_status s;
     size_t n = nslots;
-    if ((s = ensure(c, c->overflow, (size_t)overflow_depth(c) * stack_threads(c, nslots) * sizeof(uint2)))) return s;
+    if ((s = ensure(c, c->overflow, (size_t)overflow_depth(c) * trace_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
     if ((s = ensure(c, c->rayO, n * 16))) return s;
     if ((s = ensure(c, c->rayD, n * 16))) return s;
     if ((s = ensure(c, c->rayS, n * 16))) return s;
@@ -216,7 +203,7 @@ PathBuffers make_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint
     P.contrib = (float4*)c->contrib.p; P.depth = (uint32_t*)c->depth.p; P.accum = (float4*)c->accum.p;
     P.queues = (uint32_t*)c->queues.p; P.shadowQueue = (uint32_t*)c->shadowQueue.p; P.counters = (uint32_t*)c->counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots;
-    P.overflow = (uint2*)c->overflow.p; P.overflowStride = stack_threads(c, nslots); P.overflowDepth = overflow_depth(c);
+    P.overflow = (uint2*)c->overflow.p; P.overflowStride = trace_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
 }
 
@@ -224,10 +211,6 @@ template <bool PRIMARY, typename... Args>
 void launch_extend(bool exact, bool count, dim3 g, hipStream_t st, Args... a) {
     if (exact) { if (count) k_extend<true, true, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...); else k_extend<true, false, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...); }
     else { if (count) k_extend<false, true, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...); else k_extend<false, false, PRIMARY><<<g, RT_BLOCK, 0, st>>>(a...); }
-}
-template <bool PRIMARY, typename... Args>
-void launch_extend_dyn(bool count, dim3 g, hipStream_t st, Args... a) {
-    if (count) k_extend_dyn<true, PRIMARY><<<g, RT_DYN_BLOCK, 0, st>>>(a...); else k_extend_dyn<false, PRIMARY><<<g, RT_DYN_BLOCK, 0, st>>>(a...);
 }
 template <typename... Args>
 void launch_shadow(bool exact, bool count, dim3 g, hipStream_t st, Args... a) {
@@ -267,7 +250,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     // kernels, bounded by a slot budget.
     const uint32_t maxB = (uint32_t)c->maxBounces;
     uint32_t S_ = (uint32_t)(c->samplesPerPass < 1 ? 1 : c->samplesPerPass);
-    const uint64_t slotBudget = 1ull << 27;   // ~210 B of path state + log per slot
+    const uint64_t slotBudget = 1ull << 28;   // ~210 B of path state + log per slot
     if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
     if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
     const uint32_t nslots = S_ * sps;
@@ -303,8 +286,6 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
     uint32_t* qcount = P.counters;
     uint32_t* scount = P.counters + (maxB + 1);
-    const bool dyn = !exact && c->dynamicFetch != 0;
-    const int refill = refill_arg(c);
     // Optional per-kernel-class timing with HIP events on the launch stream (ring of pairs, drained lazily).
     const bool timeKernels = c->timeKernels != 0;
     double msAcc[3] = {0.0, 0.0, 0.0};
@@ -344,12 +325,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             uint32_t* qin = b == 0 ? nullptr : P.queues + (size_t)(b & 1) * nslots;   // bounce 0: identity queue
             uint32_t* qout = P.queues + (size_t)((b + 1) & 1) * nslots;
             rt_ctx::EvPair* e = evBegin(0);
-            if (dyn) {
-                const dim3 dg(dyn_blocks(c, Pp.nslots));
-                if (b == 0) launch_extend_dyn<true>(count, dg, st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, refill, dst);
-                else launch_extend_dyn<false>(count, dg, st, S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refill, dst);
-            }
-            else if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
+            if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
             else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
             evEnd(e);
             e = evBegin(1);
@@ -358,12 +334,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             evEnd(e);
             if (F.numLights > 0) {
                 e = evBegin(2);
-                if (dyn) {
-                    const dim3 dg(dyn_blocks(c, Pp.nslots));
-                    if (count) k_shadow_dyn<true><<<dg, RT_DYN_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refill, dst);
-                    else k_shadow_dyn<false><<<dg, RT_DYN_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refill, dst);
-                }
-                else launch_shadow(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
+                launch_shadow(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
                 evEnd(e);
             }
         }
@@ -455,8 +426,6 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "countVisits")) c->countVisits = v;
     else if (name_is(name, "samplesPerPass")) c->samplesPerPass = v;
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
-    else if (name_is(name, "dynamicFetch")) c->dynamicFetch = v;
-    else if (name_is(name, "refillIdle")) c->refillIdle = v;
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
 }
 rt_status rt_set_float(rt_ctx* c, const char* name, float v) {
@@ -589,11 +558,7 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, (const float*)dO.p, (const float*)dD.p, (uint32_t)n, P.queues, P.counters);
     FrameParams F0;
     std::memset(&F0, 0, sizeof F0);
-    if (!exact && c->dynamicFetch != 0)
-        launch_extend_dyn<false>(count, dim3(dyn_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues, (const uint32_t*)P.counters,
-                                 0, 0u, refill_arg(c), dst);
-    else
-        launch_extend<false>(exact, count, dim3(trace_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues,
+    launch_extend<false>(exact, count, dim3(trace_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues,
                              (const uint32_t*)P.counters, 0, 0u, dst);
     hipError_t e = hipStreamSynchronize(st);
     std::vector<float> h4(n * 4);
