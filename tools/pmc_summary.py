@@ -10,16 +10,18 @@ from collections import defaultdict
 out = sys.argv[1]
 tot = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(int)
+percall = defaultdict(int)
 seen = set()
 for f in sorted(glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (f, r["Dispatch_Id"])
-        if key not in seen and r["Counter_Name"] in ("SQ_WAVES", "FETCH_SIZE"):
+        if key not in seen:
             seen.add(key)
-            if r["Counter_Name"] == "SQ_WAVES":
-                calls[k] += 1
+            percall[(f, k)] += 1
+for (f, k), n in percall.items():
+    calls[k] = max(calls[k], n)       # every pass runs the same command: dispatches per kernel = count in one pass
 names = sorted({c for k in tot for c in tot[k]})
 print("| kernel | dispatches | " + " | ".join(names) + " |")
 print("|---|---|" + "---|" * len(names))
