@@ -196,8 +196,21 @@ def main():
         n_launch = max(1, agg["launches_extend"])
         avg_ms = agg["ms_extend"] / n_launch
         achieved = (bytes_per_ray * ext_rays / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 wraps the
+        # command): they come from the committed counter pass of this same command, tools/profile_round.sh ->
+        # profiles/traffic_<workload>.json (FETCH_SIZE x 2 + WRITE_SIZE per launch, MI355X_MICROARCH.md HBM section).
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if not args.overridden and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj["kernels"]["k_extend"]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % args.workload
+            except Exception:
+                traffic = None
         roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "alg_bytes_per_launch": round(bytes_per_ray * ext_rays / n_launch, 1),
                     "alg_bytes_per_ray": round(bytes_per_ray, 1), "avg_launch_ms": round(avg_ms, 4),
                     "launches": agg["launches_extend"], "rays_per_launch": round(ext_rays / n_launch, 1),
                     "nodes_per_ray": round(c["node_visits"] / max(1, ext_rays_c), 2),
