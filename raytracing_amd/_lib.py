@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_core.so")
+# RT_CORE_LIB: another build of the same library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("RT_CORE_LIB") or os.path.join(_HERE, "librt_core.so")
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_buffer", "rt_set_int", "rt_set_float",
            "rt_set_vec2", "rt_set_vec3", "rt_set_vec4", "rt_set_mat4", "rt_resize", "rt_create_texture",

@@ -1,0 +1,70 @@
+// Micro-benchmark: cost of per-lane gathers from a small (cache-resident) table on gfx950, the access pattern of BVH
+// node fetches.  Reports cycles per wave-instruction per CU for global_load_dword/x2/x4 and ds_read_b128 with random
+// or uniform lane addresses and with part of the lanes masked off.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// MODE 0: 4 x dwordx4 from one 64-B record per lane (a node fetch)   MODE 1: 1 x dwordx4   MODE 2: 1 x dword
+// MODE 3: 4 x ds_read_b128 from an LDS copy (64-B records)           MODE 4: 2 x dwordx4 (32-B record)
+template <int MODE>
+__global__ __launch_bounds__(256) void k(const float4* __restrict__ table, uint32_t nrec, int iters, int activeLanes, int uniform, float* out) {
+    __shared__ float4 lds[MODE == 3 ? 2048 * 4 : 1];
+    if (MODE == 3) { for (uint32_t i = threadIdx.x; i < 2048 * 4; i += 256) lds[i] = table[i % (nrec * 4)]; __syncthreads(); }
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t x = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    float acc = 0.f;
+    if ((int)lane < activeLanes) {
+        for (int i = 0; i < iters; i++) {
+            x = x * 1664525u + 1013904223u;
+            uint32_t r = uniform ? (uint32_t)(i * 7919) % nrec : (x >> 8) % nrec;
+            if (MODE == 3) r &= 2047;
+            float4 a, b, c, d;
+            if (MODE == 0) { const float4* p = table + (size_t)r * 4; a = p[0]; b = p[1]; c = p[2]; d = p[3]; acc += a.x + b.y + c.z + d.w; }
+            else if (MODE == 1) { a = table[(size_t)r * 4]; acc += a.x + a.w; }
+            else if (MODE == 2) { acc += reinterpret_cast<const float*>(table)[(size_t)r * 16]; }
+            else if (MODE == 3) { const float4* p = lds + r * 4; a = p[0]; b = p[1]; c = p[2]; d = p[3]; acc += a.x + b.y + c.z + d.w; }
+            else if (MODE == 4) { const float4* p = table + (size_t)r * 4; a = p[0]; b = p[1]; acc += a.x + b.y; }
+            // dependent chain like a traversal: next index depends on the data
+            x += (uint32_t)(acc != 12345.678f);
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int MODE>
+void run(const char* name, const float4* table, uint32_t nrec, float* out, int instrPerIter) {
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const int blocks = 256 * 8, iters = 2000;
+    for (int uniform = 0; uniform < 2; uniform++)
+        for (int lanes : {64, 32, 16, 4}) {
+            k<MODE><<<blocks, 256>>>(table, nrec, 10, lanes, uniform, out);
+            CHK(hipEventRecord(e0));
+            k<MODE><<<blocks, 256>>>(table, nrec, iters, lanes, uniform, out);
+            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+            float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+            double waveIters = (double)blocks * 4 * iters;               // wave-level iterations
+            double cyclesPerCU = ms * 1e-3 * 2.4e9;                       // assumed 2.4 GHz
+            double perIter = cyclesPerCU / (waveIters / 256.0);          // CU-cycles per wave-iteration
+            printf("%-28s %s lanes %2d: %8.3f ms  %7.1f CU-cycles per wave-iteration (%d vmem/lds instr) -> %6.1f per instr, %5.2f per active lane-instr\n",
+                   name, uniform ? "uniform" : "random ", lanes, ms, perIter, instrPerIter, perIter / instrPerIter, perIter / instrPerIter / lanes);
+        }
+}
+
+int main() {
+    const uint32_t nrec = 1600;          // ~100 KB of 64-B records: scene-4-sized node array
+    std::vector<float> h(nrec * 16);
+    for (size_t i = 0; i < h.size(); i++) h[i] = (float)(i % 97) * 0.5f;
+    float4* table; float* out;
+    CHK(hipMalloc(&table, nrec * 64)); CHK(hipMalloc(&out, 256 * 8 * 256 * 4));
+    CHK(hipMemcpy(table, h.data(), nrec * 64, hipMemcpyHostToDevice));
+    run<0>("4 x global_load_dwordx4", table, nrec, out, 4);
+    run<4>("2 x global_load_dwordx4", table, nrec, out, 2);
+    run<1>("1 x global_load_dwordx4", table, nrec, out, 1);
+    run<2>("1 x global_load_dword", table, nrec, out, 1);
+    run<3>("4 x ds_read_b128", table, nrec, out, 4);
+    return 0;
+}
