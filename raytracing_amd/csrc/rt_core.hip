@@ -42,7 +42,6 @@ struct rt_ctx {
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
     int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 128;
-    int32_t ldsNodes = 1, ldsBlocksPerCU = 4;
 
     // device scene
     DevBuf dNodes, dTris, dShade, dMaterials, dVertices, dLights, dTexDescs;
@@ -157,7 +156,6 @@ SceneView make_view(rt_ctx* c, bool exact) {
     S.materials = (const RefMaterial*)c->dMaterials.p; S.vertices = (const RefVertex*)c->dVertices.p;
     S.lights = (const RefLight*)c->dLights.p; S.textures = (const TexDesc*)c->dTexDescs.p;
     S.n_textures = (uint32_t)c->textures.size();
-    S.n_nodes = (uint32_t)c->cs.nodes.size();
     S.rootChild = c->cs.rootChild;
     for (int k = 0; k < 3; k++) { S.rootLo[k] = c->cs.rootLo[k]; S.rootHi[k] = c->cs.rootHi[k]; }
     S.cullAbs = 1e-5f * c->cs.sceneScale;
@@ -173,18 +171,9 @@ uint32_t trace_blocks(rt_ctx* c, uint32_t nslots) {
     uint32_t persistent = (uint32_t)c->numCUs * (uint32_t)c->blocksPerCU;
     return slotBlocks < persistent ? slotBlocks : persistent;
 }
-// grid of the LDS-resident-BVH traversal kernels (rt_trace_lds.hip.h): 1024-thread workgroups, one resident per CU
-uint32_t lds_blocks(rt_ctx* c, uint32_t nItems) {
-    uint32_t itemBlocks = (nItems + RT_LDS_BLOCK - 1) / RT_LDS_BLOCK;
-    uint32_t most = (uint32_t)c->numCUs * (uint32_t)std::max(1, (int)c->ldsBlocksPerCU);
-    return std::max(1u, itemBlocks < most ? itemBlocks : most);
-}
-uint32_t stack_threads(rt_ctx* c, uint32_t nslots) {
-    return std::max(trace_blocks(c, nslots) * RT_BLOCK, lds_blocks(c, nslots) * RT_LDS_BLOCK);
-}
 uint32_t overflow_depth(rt_ctx* c) {
     // ordered traversal keeps at most one pending sibling per level: depth <= tree depth
-    int need = (int)c->cs.maxDepth + 1 - std::min(RT_LDS_STACK, RT_LDS_DEPTH);
+    int need = (int)c->cs.maxDepth + 1 - RT_LDS_STACK;
     if (need < 0) need = 0;
     if (need > RT_SPILL_STACK) need = RT_SPILL_STACK;
     return (uint32_t)need;
@@ -193,7 +182,7 @@ uint32_t overflow_depth(rt_ctx* c) {
 rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
     rt_status s;
     size_t n = nslots;
-    if ((s = ensure(c, c->overflow, (size_t)overflow_depth(c) * stack_threads(c, nslots) * sizeof(uint2)))) return s;
+    if ((s = ensure(c, c->overflow, (size_t)overflow_depth(c) * trace_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
     if ((s = ensure(c, c->rayO, n * 16))) return s;
     if ((s = ensure(c, c->rayD, n * 16))) return s;
     if ((s = ensure(c, c->rayS, n * 16))) return s;
@@ -214,7 +203,7 @@ PathBuffers make_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint
     P.contrib = (float4*)c->contrib.p; P.depth = (uint32_t*)c->depth.p; P.accum = (float4*)c->accum.p;
     P.queues = (uint32_t*)c->queues.p; P.shadowQueue = (uint32_t*)c->shadowQueue.p; P.counters = (uint32_t*)c->counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots;
-    P.overflow = (uint2*)c->overflow.p; P.overflowStride = stack_threads(c, nslots); P.overflowDepth = overflow_depth(c);
+    P.overflow = (uint2*)c->overflow.p; P.overflowStride = trace_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
 }
 
@@ -297,7 +286,6 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
     uint32_t* qcount = P.counters;
     uint32_t* scount = P.counters + (maxB + 1);
-    const bool lds = !exact && c->ldsNodes != 0;
     // Optional per-kernel-class timing with HIP events on the launch stream (ring of pairs, drained lazily).
     const bool timeKernels = c->timeKernels != 0;
     double msAcc[3] = {0.0, 0.0, 0.0};
@@ -337,17 +325,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             uint32_t* qin = b == 0 ? nullptr : P.queues + (size_t)(b & 1) * nslots;   // bounce 0: identity queue
             uint32_t* qout = P.queues + (size_t)((b + 1) & 1) * nslots;
             rt_ctx::EvPair* e = evBegin(0);
-            if (lds) {
-                const dim3 lg(lds_blocks(c, Pp.nslots));
-                if (b == 0) {
-                    if (count) k_extend_lds<true, true><<<lg, RT_LDS_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
-                    else k_extend_lds<false, true><<<lg, RT_LDS_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
-                } else {
-                    if (count) k_extend_lds<true, false><<<lg, RT_LDS_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
-                    else k_extend_lds<false, false><<<lg, RT_LDS_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
-                }
-            }
-            else if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
+            if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
             else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
             evEnd(e);
             e = evBegin(1);
@@ -356,12 +334,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             evEnd(e);
             if (F.numLights > 0) {
                 e = evBegin(2);
-                if (lds) {
-                    const dim3 lg(lds_blocks(c, Pp.nslots));
-                    if (count) k_shadow_lds<true><<<lg, RT_LDS_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
-                    else k_shadow_lds<false><<<lg, RT_LDS_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
-                }
-                else launch_shadow(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
+                launch_shadow(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
                 evEnd(e);
             }
         }
@@ -453,8 +426,6 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "countVisits")) c->countVisits = v;
     else if (name_is(name, "samplesPerPass")) c->samplesPerPass = v;
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
-    else if (name_is(name, "ldsNodes")) c->ldsNodes = v;
-    else if (name_is(name, "ldsBlocksPerCU")) c->ldsBlocksPerCU = v < 1 ? 1 : v;
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
 }
 rt_status rt_set_float(rt_ctx* c, const char* name, float v) {
@@ -587,12 +558,7 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, (const float*)dO.p, (const float*)dD.p, (uint32_t)n, P.queues, P.counters);
     FrameParams F0;
     std::memset(&F0, 0, sizeof F0);
-    if (!exact && c->ldsNodes != 0) {
-        const dim3 lg(lds_blocks(c, nslots));
-        if (count) k_extend_lds<true, false><<<lg, RT_LDS_BLOCK, 0, st>>>(S, F0, P, (const uint32_t*)P.queues, (const uint32_t*)P.counters, 0, 0u, dst);
-        else k_extend_lds<false, false><<<lg, RT_LDS_BLOCK, 0, st>>>(S, F0, P, (const uint32_t*)P.queues, (const uint32_t*)P.counters, 0, 0u, dst);
-    } else
-        launch_extend<false>(exact, count, dim3(trace_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues,
+    launch_extend<false>(exact, count, dim3(trace_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues,
                              (const uint32_t*)P.counters, 0, 0u, dst);
     hipError_t e = hipStreamSynchronize(st);
     std::vector<float> h4(n * 4);

@@ -20,9 +20,6 @@
 namespace rt {
 
 #define RT_BLOCK 256
-#ifndef RT_TRAV_OCC
-#define RT_TRAV_OCC
-#endif
 
 struct PathBuffers {
     float4* rayO;        // o.xyz, w = flag bits (bit0 refracting)
@@ -260,14 +257,6 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, cons
             int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             float t0, t1;
             bool p0, p1;
-#ifdef RT_EXP_EXTRA_LOAD
-            { float4 xx = np[(cur & 1) ? -4 : 4]; asm volatile("" :: "v"(xx.x), "v"(xx.y), "v"(xx.z), "v"(xx.w)); }
-#endif
-#ifdef RT_EXP_EXTRA_VALU
-            { float z = n0.x;
-              for (int q = 0; q < RT_EXP_EXTRA_VALU; q++) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(z) : "v"(n0.y));
-              asm volatile("" :: "v"(z)); }
-#endif
             if (FAST) {
                 float x0, x1;
                 slab_pair(R, n0, n1, n2, t0, x0, t1, x1);
@@ -411,7 +400,7 @@ __device__ __forceinline__ bool primary_ray(const FrameParams& F, const PathBuff
 // queue == nullptr: identity (bounce 0).  rayCount > 0 overrides the number of rays added to the counters
 // (bounce 0: region pixels, not slots).
 template <bool EXACT, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(RT_BLOCK) RT_TRAV_OCC void k_extend(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ queue,
                                                      const uint32_t* __restrict__ count, int rBase, uint32_t rayCount,
                                                      DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
@@ -773,7 +762,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
 
 // shader.comp:453-484: the shadow lineCast of every log entry awaiting one; the entry becomes "add" (2) or "none" (0).
 template <bool EXACT, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) RT_TRAV_OCC void k_shadow(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
                                                      int bounce, DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
     const Stack stk = make_stack(lds, P);
@@ -886,4 +875,3 @@ __global__ __launch_bounds__(RT_BLOCK) void k_load_rays(PathBuffers P, const flo
 
 }  // namespace rt
 
-#include "rt_trace_lds.hip.h"

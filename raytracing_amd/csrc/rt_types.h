@@ -109,7 +109,6 @@ struct SceneView {
     const RefLight* lights;
     const TexDesc* textures;
     uint32_t n_textures;
-    uint32_t n_nodes;              // CNode records (breadth-first order)
     int32_t rootChild;             // >= 0 internal CNode index, < 0 leaf code (root is a leaf)
     float rootLo[3], rootHi[3];    // reference box of node 0 (tested first, shader.comp:249-256)
     float cullAbs;                 // absolute slack of the distance cull (traversalMode 0)
