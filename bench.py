@@ -26,6 +26,7 @@ WORKLOADS = {
     "c1": dict(scene=3, width=512, height=512, spp=64, bounces=8, grid=0, desc="configs[0]: scene 3 (box + roughSphere, 330 tris, point light, textured)"),
     "c2": dict(scene=4, width=1920, height=1080, spp=1024, bounces=8, grid=0, desc="configs[1]: scene 4 (scene4.gltf, 4802 tris, sun light)"),
     "c3": dict(scene=7, width=1920, height=1080, spp=256, bounces=16, grid=0, desc="configs[2]: scene 7 (RayTracing.gltf, 44722 tris, rough glass, sun light; spp not given by BASELINE, 256 used)"),
+    "c5": dict(scene=7, width=3840, height=2160, spp=1024, bounces=8, grid=0, desc="configs[4]: scene 7 orbit (Renderer.cpp:187-193), one 4K frame per step, frame index = step"),
     "c4": dict(scene=0, width=1920, height=1080, spp=256, bounces=8, grid=3162, desc="configs[3]: synthetic height field, 2*grid^2 triangles, sun light"),
 }
 
@@ -152,7 +153,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    frame_no = [0]
+
     def step():
+        if args.workload == "c5":                    # the camera path of the offline render: frame f of the orbit
+            frame_no[0] += 1
+            pos, ori = S.orbit_camera(frame_no[0])
+            S.set_camera(cs, pos, ori, W, H, 45.0)
         cs.dispatch_region(0, 0, W, H, r0, r1)       # returns with the images complete
         if world > 1:
             dist.reduce(color, dst=0, op=dist.ReduceOp.SUM)

@@ -182,3 +182,23 @@ def test_write_image_and_device_pointer(scene4):
     assert np.array_equal(cs.get_image(0), img)
     assert cs.image_device_ptr(0) != 0 and cs.image_device_ptr(3) != cs.image_device_ptr(0)
     cs.Delete()
+
+
+def test_camera_path_driver_writes_reference_frames(oracle_lib, models_root, tmp_path):
+    """Config 5's driver (raytracing_amd/render_path.py = Renderer::Start/NextFrame/UpdateCamera): frame 0 with the
+    default camera, frame f >= 1 with the orbit camera of frame f, 8-bit PPM frames as Renderer.cpp:103-124 converts them."""
+    from raytracing_amd import render_path
+    W, H, spp, b = 64, 36, 2, 4
+    render_path.main(["--scene", "4", "--models", models_root, "--width", str(W), "--height", str(H), "--spp", str(spp),
+                      "--bounces", str(b), "--frames", "3", "--out", str(tmp_path)])
+    d = tmp_path / ("Scene-4_spp-%d_bounces-%d" % (spp, b))
+    sc = oracle_lib.load_scene(models_root, 4)
+    for f in range(3):
+        raw = (d / ("frame_%04d.ppm" % f)).read_bytes()
+        hdr = b"P6\n%d %d\n255\n" % (W, H)
+        assert raw.startswith(hdr)
+        got = np.frombuffer(raw[len(hdr):], np.uint8).reshape(H, W, 3)
+        cam = oracle_lib.DEFAULT_CAMERA if f == 0 else render_path.frame_camera(f)
+        want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, camera=cam, math_mode=1))["color"]
+        ref8 = (np.nan_to_num(np.clip(want[::-1, :, :3], 0, 1), nan=0.0) * np.float32(255)).astype(np.uint8)
+        assert np.array_equal(got, ref8), f
