@@ -56,7 +56,7 @@ struct rt_ctx {
     bool primValid = false;
 
     // path state
-    DevBuf rayO, rayD, rayS, hit, contrib, depth, accum, queues, shadowQueue, counters, dStats, overflow;
+    DevBuf rayOD, rayS, hit, shadeLoc, contrib, depth, accum, queues, shadowQueue, counters, dStats, overflow;
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
 
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; bool used = false; };
@@ -183,10 +183,10 @@ rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint
     rt_status s;
     size_t n = nslots;
     if ((s = ensure(c, c->overflow, (size_t)overflow_depth(c) * trace_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
-    if ((s = ensure(c, c->rayO, n * 16))) return s;
-    if ((s = ensure(c, c->rayD, n * 16))) return s;
+    if ((s = ensure(c, c->rayOD, n * 32))) return s;
+    if ((s = ensure(c, c->shadeLoc, n * 16))) return s;
     if ((s = ensure(c, c->rayS, n * 16))) return s;
-    if ((s = ensure(c, c->hit, n * 16))) return s;
+    if ((s = ensure(c, c->hit, n * 8))) return s;
     if ((s = ensure(c, c->contrib, n * 16 * lightSlots * std::max<uint32_t>(1, maxBounces)))) return s;
     if ((s = ensure(c, c->depth, n * 4))) return s;
     if ((s = ensure(c, c->accum, (size_t)slotsPerSample * 16))) return s;
@@ -199,7 +199,7 @@ rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint
 
 PathBuffers make_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots) {
     PathBuffers P;
-    P.rayO = (float4*)c->rayO.p; P.rayD = (float4*)c->rayD.p; P.rayS = (float4*)c->rayS.p; P.hit = (float4*)c->hit.p;
+    P.rayOD = (float4*)c->rayOD.p; P.rayS = (float4*)c->rayS.p; P.hit = (float2*)c->hit.p; P.shadeLoc = (float4*)c->shadeLoc.p;
     P.contrib = (float4*)c->contrib.p; P.depth = (uint32_t*)c->depth.p; P.accum = (float4*)c->accum.p;
     P.queues = (uint32_t*)c->queues.p; P.shadowQueue = (uint32_t*)c->shadowQueue.p; P.counters = (uint32_t*)c->counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots;
@@ -238,6 +238,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint32_t tilesY = (h + 7) / 8;
     const uint32_t sps = (uint32_t)F.tilesX * tilesY * 64u;            // slots per sample
     F.numLights = c->numLights < 0 ? 0 : c->numLights; F.hasSun = c->hasSun;
+    for (int l = 0; l < F.numLights && (size_t)(l + 1) * 48 <= c->slotHost[RT_SLOT_LIGHTS].size(); l++)
+        if (((const RefLight*)c->slotHost[RT_SLOT_LIGHTS].data())[l].lightType == 0u) F.anyPoint = 1;
     for (int k = 0; k < 3; k++) { F.camPos[k] = c->camPos[k]; F.camForward[k] = c->camForward[k]; F.camRight[k] = c->camRight[k]; F.camUp[k] = c->camUp[k]; }
     F.aspect = c->aspect;
     F.tanHalfFov = tanf((c->fov * 0.017453292519943295f) / 2.0f);   // tan(radians(fov) / 2.0), shader.comp:321
@@ -391,7 +393,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->dNodes, &c->dTris, &c->dShade, &c->dMaterials, &c->dVertices, &c->dLights, &c->dTexDescs,
-                      &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->rayO, &c->rayD, &c->rayS,
+                      &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->rayOD, &c->shadeLoc, &c->rayS,
                       &c->hit, &c->contrib, &c->depth, &c->accum, &c->queues, &c->shadowQueue, &c->counters, &c->dStats, &c->overflow};
     for (DevBuf* b : bufs) b->release();
     for (auto& t : c->textures) t.data.release();
@@ -561,16 +563,23 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     launch_extend<false>(exact, count, dim3(trace_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues,
                              (const uint32_t*)P.counters, 0, 0u, dst);
     hipError_t e = hipStreamSynchronize(st);
-    std::vector<float> h4(n * 4);
-    if (e == hipSuccess) e = hipMemcpy(h4.data(), P.hit, n * 16, hipMemcpyDeviceToHost);
+    std::vector<float> h2(n * 2);
+    if (e == hipSuccess) e = hipMemcpy(h2.data(), P.hit, n * 8, hipMemcpyDeviceToHost);
     DeviceStats hs; std::memset(&hs, 0, sizeof hs);
     if (e == hipSuccess) e = hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost);
     dO.release(); dD.release();
     if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("rt_trace_rays: ") + hipGetErrorString(e));
     for (uint64_t i = 0; i < n; i++) {
-        int32_t id; std::memcpy(&id, &h4[i * 4 + 3], 4);
+        int32_t id; std::memcpy(&id, &h2[i * 2 + 1], 4);
         tri[i] = id;
-        if (hits) { hits[i * 3] = h4[i * 4]; hits[i * 3 + 1] = h4[i * 4 + 1]; hits[i * 3 + 2] = h4[i * 4 + 2]; }
+        if (hits) {
+            // hitLoc = orig + dir * t (shader.comp:122), the same float32 operations the kernels use (-ffp-contract=off)
+            const float t = h2[i * 2];
+            for (int k = 0; k < 3; k++) {
+                volatile float prod = dirs[i * 3 + k] * t;
+                hits[i * 3 + k] = id >= 0 ? origins[i * 3 + k] + prod : 0.f;
+            }
+        }
     }
     std::memset(&c->stats, 0, sizeof c->stats);
     c->stats.rays_primary = hs.rays_primary + hs.rays_bounce; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;

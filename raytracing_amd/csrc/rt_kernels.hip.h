@@ -22,10 +22,11 @@ namespace rt {
 #define RT_BLOCK 256
 
 struct PathBuffers {
-    float4* rayO;        // o.xyz, w = flag bits (bit0 refracting)
-    float4* rayD;        // d.xyz
+    // Path state is laid out by 32-byte sectors, the unit the CU's vector-memory path charges for:
+    float4* rayOD;       // [2*slot] = (o.xyz, d.x), [2*slot+1] = (d.y, d.z, flag bits (bit0 refracting), 0): one sector per ray
     float4* rayS;        // strength.xyz
-    float4* hit;         // hitLoc.xyz, w = reference triangle index bits (-1 miss)
+    float2* hit;         // (t, reference triangle index bits: -1 miss, -2 dead slot); hitLoc = o + d * t is recomputed
+    float4* shadeLoc;    // hitLoc of the bounce being shaded, written only when a point light needs it (k_shadow)
     float4* contrib;     // contribution log [maxBounces][lightSlots][nslots]: rgb, w = 0 none / 1 awaiting shadow ray / 2 add
     uint32_t* depth;     // [nslots] bounces shaded so far by the slot's path (log entries [0, depth) are valid)
     float4* accum;       // [slotsPerSample] running pixel colour (the shader's `color`), survives passes
@@ -37,6 +38,15 @@ struct PathBuffers {
     uint32_t nslots;     // slots in flight = samples per pass x slotsPerSample
     uint32_t slotsPerSample, lightSlots;   // lightSlots = max(1, numLights)
 };
+
+__device__ __forceinline__ void load_ray(const PathBuffers& P, uint32_t slot, v3& o, v3& d, uint32_t& flags) {
+    float4 a = P.rayOD[2u * slot], b = P.rayOD[2u * slot + 1u];
+    o = mk(a.x, a.y, a.z); d = mk(a.w, b.x, b.y); flags = __float_as_uint(b.z);
+}
+__device__ __forceinline__ void store_ray(const PathBuffers& P, uint32_t slot, v3 o, v3 d, uint32_t flags) {
+    P.rayOD[2u * slot] = make_float4(o.x, o.y, o.z, d.x);
+    P.rayOD[2u * slot + 1u] = make_float4(d.y, d.z, __uint_as_float(flags), 0.f);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Block-aggregated stream compaction for RT_ITEMS flags per thread and NQ output queues:
@@ -415,18 +425,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F,
             slot = i;
             int px, py, r;
             ro = ld3(F.camPos);
-            if (!primary_ray(F, P, rBase, slot, &px, &py, &r, &rd)) { P.hit[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-2)); continue; }
+            if (!primary_ray(F, P, rBase, slot, &px, &py, &r, &rd)) { P.hit[slot] = make_float2(0.f, __int_as_float(-2)); continue; }
         } else {
             slot = queue[i];
-            float4 o4 = P.rayO[slot], d4 = P.rayD[slot];
-            ro = mk(o4.x, o4.y, o4.z); rd = mk(d4.x, d4.y, d4.z);
+            uint32_t fl;
+            load_ray(P, slot, ro, rd, fl);
         }
         HitRec best;
         uint32_t before = nNodes + nTris;
         if (__all(ray_is_plain(ro, rd))) closest_hit<EXACT, COUNT, true>(S, ro, rd, stk, best, nNodes, nTris, wSteps);
         else closest_hit<EXACT, COUNT, false>(S, ro, rd, stk, best, nNodes, nTris, wSteps);
         if (COUNT) { uint32_t steps = nNodes + nTris - before; if (steps > maxSteps) maxSteps = steps; }
-        P.hit[slot] = make_float4(best.loc.x, best.loc.y, best.loc.z, __int_as_float(best.ref));
+        P.hit[slot] = make_float2(best.t, __int_as_float(best.ref));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(PRIMARY ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)(rayCount ? rayCount : n));
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
         uint32_t slot = 0;
         if (live) {
             slot = queue ? queue[i] : i;
-            float4 h4 = P.hit[slot];
+            float2 h2 = P.hit[slot];
             v3 rayLoc, rayDir, strength;
             bool refracting = false;
             int px, py, r;
@@ -539,13 +549,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 rayLoc = ld3(F.camPos);
                 strength = mk(F.initialStrength, F.initialStrength, F.initialStrength);
             } else {
-                float4 o4 = P.rayO[slot], d4 = P.rayD[slot], s4 = P.rayS[slot];
-                rayLoc = mk(o4.x, o4.y, o4.z); rayDir = mk(d4.x, d4.y, d4.z); strength = mk(s4.x, s4.y, s4.z);
-                refracting = (__float_as_uint(o4.w) & RT_FLAG_REFRACTING) != 0u;
+                float4 s4 = P.rayS[slot];
+                uint32_t fl;
+                load_ray(P, slot, rayLoc, rayDir, fl);
+                strength = mk(s4.x, s4.y, s4.z);
+                refracting = (fl & RT_FLAG_REFRACTING) != 0u;
                 r = rBase + (int)(slot / P.slotsPerSample);
                 slot_to_pixel(F, slot % P.slotsPerSample, &px, &py);
             }
-            int ref = __float_as_int(h4.w);
+            int ref = __float_as_int(h2.y);
             v3 camPos = ld3(F.camPos);
             float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;   // entry of light l at logp[l * nslots]
             P.depth[slot] = ref == -2 ? 0u : (uint32_t)bounce + 1u;
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * P.nslots] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r == 0 && bounce == 0 && primTri) primTri[(size_t)py * F.width + px] = -1;
             } else {
-                v3 hitLoc = mk(h4.x, h4.y, h4.z);
+                v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122)
                 const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
                 float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4], q5 = sp[5], q6 = sp[6];
                 v3 a = mk(q0.x, q0.y, q0.z), b = mk(q0.w, q1.x, q1.y), c = mk(q1.z, q1.w, q2.x);
@@ -720,13 +732,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                     strength = strength * mk(gclamp(baseColor.x, 0.f, 1.f), gclamp(baseColor.y, 0.f, 1.f), gclamp(baseColor.z, 0.f, 1.f));
                 bool active = !(length3(strength) < F.strengthCutoff);
                 cont = active && (bounce + 1 < F.maxBounces);
-                if (cont || wantShadow) {
-                    P.rayO[slot] = make_float4(rayLoc.x, rayLoc.y, rayLoc.z, __uint_as_float(refracting ? RT_FLAG_REFRACTING : 0u));
-                }
-                if (cont) {
-                    P.rayD[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.f);
-                    P.rayS[slot] = make_float4(strength.x, strength.y, strength.z, 0.f);
-                }
+                if (cont || wantShadow) store_ray(P, slot, rayLoc, rayDir, refracting ? RT_FLAG_REFRACTING : 0u);
+                if (cont) P.rayS[slot] = make_float4(strength.x, strength.y, strength.z, 0.f);
+                if (wantShadow && F.anyPoint) P.shadeLoc[slot] = make_float4(hitLoc.x, hitLoc.y, hitLoc.z, 0.f);
             }
         }
         contMask |= (cont ? 1u : 0u) << item;
@@ -770,8 +778,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
     uint32_t nNodes = 0, nTris = 0;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         uint32_t slot = P.shadowQueue[i];
-        float4 o4 = P.rayO[slot], h4 = P.hit[slot];
-        v3 o = mk(o4.x, o4.y, o4.z), hitLoc = mk(h4.x, h4.y, h4.z);
+        float4 o4 = P.rayOD[2u * slot];
+        v3 o = mk(o4.x, o4.y, o4.z), hitLoc = mk(0.f, 0.f, 0.f);
+        if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; hitLoc = mk(h4.x, h4.y, h4.z); }
         float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;
         for (int l = 0; l < F.numLights; l++) {
             float* wp = &logp[(size_t)l * P.nslots].w;
@@ -866,8 +875,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_load_rays(PathBuffers P, const flo
                                                         uint32_t* queueOut, uint32_t* countOut) {
     uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i < n) {
-        P.rayO[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.f);
-        P.rayD[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], 0.f);
+        store_ray(P, i, mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), 0u);
         queueOut[i] = i;
     }
     if (i == 0) *countOut = n;

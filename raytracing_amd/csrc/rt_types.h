@@ -120,6 +120,7 @@ struct FrameParams {
     int32_t rx, ry, rw, rh;        // region
     int32_t tilesX;                // region width in 8x8 tiles
     int32_t numLights, hasSun;
+    int32_t anyPoint;              // a point light is among the numLights lights (k_shadow then needs the shade location)
     float camPos[3], camForward[3], camRight[3], camUp[3];
     float aspect, tanHalfFov;
     int32_t samplesPerPixel, maxBounces;
