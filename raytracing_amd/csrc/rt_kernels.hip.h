@@ -531,15 +531,27 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
     uint32_t skipped = 0, pending = 0;
     for (uint32_t ch = blockIdx.x; ch < nChunks; ch += gridDim.x) {
       uint32_t contMask = 0, shadowMask = 0;
+      // The chain queue -> slot -> hit -> shading record -> material is four dependent round trips per path and this
+      // kernel has few waves to hide them (125 VGPRs), so the first two levels are taken off it: the four queue
+      // entries of this thread are fetched together, and the hit record of item k + 1 while item k is shaded.
+      static_assert(RT_ITEMS == 4, "slot prefetch below is written for 4 items");
+      const uint32_t iBase = ch * chunk + threadIdx.x;
+      uint32_t q0 = iBase, q1 = iBase + RT_BLOCK, q2 = iBase + 2 * RT_BLOCK, q3 = iBase + 3 * RT_BLOCK;
+      if (queue) {
+          q0 = q0 < n ? queue[q0] : 0u; q1 = q1 < n ? queue[q1] : 0u; q2 = q2 < n ? queue[q2] : 0u; q3 = q3 < n ? queue[q3] : 0u;
+      }
+      auto slotOf = [&](int k) { return k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3; };
+      float2 nextHit = make_float2(0.f, 0.f);
+      if (iBase < n) nextHit = P.hit[q0];
 #pragma unroll 1
       for (int item = 0; item < RT_ITEMS; item++) {
-        uint32_t i = ch * chunk + (uint32_t)item * RT_BLOCK + threadIdx.x;
+        uint32_t i = iBase + (uint32_t)item * RT_BLOCK;
         bool live = i < n;
         bool cont = false, wantShadow = false;
-        uint32_t slot = 0;
+        uint32_t slot = slotOf(item);
+        const float2 h2 = nextHit;
+        if (item + 1 < RT_ITEMS && i + RT_BLOCK < n) nextHit = P.hit[slotOf(item + 1)];
         if (live) {
-            slot = queue ? queue[i] : i;
-            float2 h2 = P.hit[slot];
             v3 rayLoc, rayDir, strength;
             bool refracting = false;
             int px, py, r;
@@ -750,8 +762,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
 #pragma unroll
       for (int k = 0; k < RT_ITEMS; k++) {
           if (flag[0][k] | flag[1][k]) {
-              uint32_t i = ch * chunk + (uint32_t)k * RT_BLOCK + threadIdx.x;
-              uint32_t slot = queue ? queue[i] : i;
+              uint32_t slot = slotOf(k);
               if (flag[0][k]) queueOut[idx[0][k]] = slot;
               if (flag[1][k]) P.shadowQueue[idx[1][k]] = slot;
           }
