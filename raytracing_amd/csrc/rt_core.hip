@@ -56,7 +56,15 @@ struct rt_ctx {
     bool primValid = false;
 
     // path state
-    DevBuf rayOD, rayS, hit, shadeLoc, contrib, depth, accum, queues, shadowQueue, counters, dStats, overflow;
+    // Up to four sets of per-pass path buffers: consecutive passes run on `passStreams` streams, so that the small, tail-dominated
+    // launches of one pass's late bounces overlap the large launches of the next pass (only k_resolve is ordered).
+    struct PathSet { DevBuf rayOD, rayS, hit, shadeLoc, contrib, depth, queues, shadowQueue, counters, overflow; };
+    static constexpr int kMaxSets = 4;
+    PathSet set[kMaxSets];
+    DevBuf accum, dStats;
+    hipStream_t extra[kMaxSets] = {nullptr, nullptr, nullptr, nullptr};     // streams of sets 1.. (set 0 uses `stream`)
+    hipEvent_t evResolve[kMaxSets] = {nullptr, nullptr, nullptr, nullptr}, evInit = nullptr;
+    int32_t passStreams = 4;
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
 
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; bool used = false; };
@@ -179,31 +187,33 @@ uint32_t overflow_depth(rt_ctx* c) {
     return (uint32_t)need;
 }
 
-rt_status ensure_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
+rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
     rt_status s;
     size_t n = nslots;
-    if ((s = ensure(c, c->overflow, (size_t)overflow_depth(c) * trace_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
-    if ((s = ensure(c, c->rayOD, n * 32))) return s;
-    if ((s = ensure(c, c->shadeLoc, n * 16))) return s;
-    if ((s = ensure(c, c->rayS, n * 16))) return s;
-    if ((s = ensure(c, c->hit, n * 8))) return s;
-    if ((s = ensure(c, c->contrib, n * 16 * lightSlots * std::max<uint32_t>(1, maxBounces)))) return s;
-    if ((s = ensure(c, c->depth, n * 4))) return s;
+    rt_ctx::PathSet& ps = c->set[which];
+    if ((s = ensure(c, ps.overflow, (size_t)overflow_depth(c) * trace_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
+    if ((s = ensure(c, ps.rayOD, n * 32))) return s;
+    if ((s = ensure(c, ps.shadeLoc, n * 16))) return s;
+    if ((s = ensure(c, ps.rayS, n * 16))) return s;
+    if ((s = ensure(c, ps.hit, n * 8))) return s;
+    if ((s = ensure(c, ps.contrib, n * 16 * lightSlots * std::max<uint32_t>(1, maxBounces)))) return s;
+    if ((s = ensure(c, ps.depth, n * 4))) return s;
     if ((s = ensure(c, c->accum, (size_t)slotsPerSample * 16))) return s;
-    if ((s = ensure(c, c->queues, n * 4 * 2))) return s;
-    if ((s = ensure(c, c->shadowQueue, n * 4))) return s;
-    if ((s = ensure(c, c->counters, (size_t)(2 * (maxBounces + 1)) * 4))) return s;
+    if ((s = ensure(c, ps.queues, n * 4 * 2))) return s;
+    if ((s = ensure(c, ps.shadowQueue, n * 4))) return s;
+    if ((s = ensure(c, ps.counters, (size_t)(2 * (maxBounces + 1)) * 4))) return s;
     if ((s = ensure(c, c->dStats, sizeof(DeviceStats)))) return s;
     return RT_OK;
 }
 
-PathBuffers make_paths(rt_ctx* c, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots) {
+PathBuffers make_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots) {
     PathBuffers P;
-    P.rayOD = (float4*)c->rayOD.p; P.rayS = (float4*)c->rayS.p; P.hit = (float2*)c->hit.p; P.shadeLoc = (float4*)c->shadeLoc.p;
-    P.contrib = (float4*)c->contrib.p; P.depth = (uint32_t*)c->depth.p; P.accum = (float4*)c->accum.p;
-    P.queues = (uint32_t*)c->queues.p; P.shadowQueue = (uint32_t*)c->shadowQueue.p; P.counters = (uint32_t*)c->counters.p;
+    rt_ctx::PathSet& ps = c->set[which];
+    P.rayOD = (float4*)ps.rayOD.p; P.rayS = (float4*)ps.rayS.p; P.hit = (float2*)ps.hit.p; P.shadeLoc = (float4*)ps.shadeLoc.p;
+    P.contrib = (float4*)ps.contrib.p; P.depth = (uint32_t*)ps.depth.p; P.accum = (float4*)c->accum.p;
+    P.queues = (uint32_t*)ps.queues.p; P.shadowQueue = (uint32_t*)ps.shadowQueue.p; P.counters = (uint32_t*)ps.counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots;
-    P.overflow = (uint2*)c->overflow.p; P.overflowStride = trace_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
+    P.overflow = (uint2*)ps.overflow.p; P.overflowStride = trace_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
 }
 
@@ -258,8 +268,14 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint32_t nslots = S_ * sps;
     const uint32_t lightSlots = (uint32_t)std::max(1, F.numLights);
 
-    if ((s = ensure_paths(c, nslots, sps, lightSlots, maxB))) return s;
-    PathBuffers P = make_paths(c, nslots, sps, lightSlots);
+    const uint32_t nPasses = (r1 - r0 + S_ - 1) / std::max(1u, S_);
+    const int nSets = (int)std::max(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t)std::max(1, (int)c->passStreams), rt_ctx::kMaxSets), nPasses));
+    PathBuffers Pset[rt_ctx::kMaxSets];
+    for (int k = 0; k < nSets; k++) {
+        if ((s = ensure_paths(c, k, nslots, sps, lightSlots, maxB))) return s;
+        Pset[k] = make_paths(c, k, nslots, sps, lightSlots);
+    }
+    PathBuffers P = Pset[0];
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;
     SceneView S = make_view(c, exact);
@@ -286,8 +302,11 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     k_init_frame<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, iAlb, iNor, iDep);
 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
-    uint32_t* qcount = P.counters;
-    uint32_t* scount = P.counters + (maxB + 1);
+    hipStream_t streams[rt_ctx::kMaxSets] = {c->stream, c->extra[1], c->extra[2], c->extra[3]};
+    if (nSets > 1) {
+        HIPCHK(c, hipEventRecord(c->evInit, st));                 // images + accumulators initialised
+        for (int k = 1; k < nSets; k++) HIPCHK(c, hipStreamWaitEvent(streams[k], c->evInit, 0));
+    }
     // Optional per-kernel-class timing with HIP events on the launch stream (ring of pairs, drained lazily).
     const bool timeKernels = c->timeKernels != 0;
     double msAcc[3] = {0.0, 0.0, 0.0};
@@ -314,9 +333,16 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         return &e;
     };
     auto evEnd = [&](rt_ctx::EvPair* e) { if (e) (void)hipEventRecord(e->b, st); };
+    uint32_t passNo = 0;
 
     for (uint32_t rBase = r0; rBase < r1; rBase += S_) {
         const uint32_t inPass = std::min(S_, r1 - rBase);
+        // consecutive passes rotate over the streams and buffer sets; k_resolve alone is ordered
+        const int ks = (int)(passNo % (uint32_t)nSets);
+        P = Pset[ks];
+        st = streams[ks];
+        uint32_t* qcount = P.counters;
+        uint32_t* scount = P.counters + (maxB + 1);
         PathBuffers Pp = P;
         Pp.nslots = inPass * sps;                  // a short last pass uses its own (smaller) log strides
         const uint32_t passBlocks = (Pp.nslots + RT_BLOCK - 1) / RT_BLOCK;
@@ -340,11 +366,16 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                 evEnd(e);
             }
         }
-        k_resolve<<<pixBlocks, RT_BLOCK, 0, st>>>(Pp, (int)inPass, (int)maxB);
+        // the pixel sum runs over samples in order (shader.comp:312): this pass's replay follows the previous pass's
+        if (nSets > 1 && passNo > 0) HIPCHK(c, hipStreamWaitEvent(st, c->evResolve[(ks + nSets - 1) % nSets], 0));
+        // (maxBounces == 0: nothing was shaded, so the per-slot depths k_resolve reads were never written)
+        if (maxB > 0) k_resolve<<<pixBlocks, RT_BLOCK, 0, st>>>(Pp, (int)inPass, (int)maxB);
+        if (nSets > 1) HIPCHK(c, hipEventRecord(c->evResolve[ks], st));
+        passNo++;
     }
-    k_finalize<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, (float4*)c->img[0].p);
+    k_finalize<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, (float4*)c->img[0].p);     // on the last pass's stream, after its replay
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(st));
+    for (int k = 0; k < nSets; k++) HIPCHK(c, hipStreamSynchronize(streams[k]));
     if (timeKernels) for (auto& e : c->evRing) evDrain(e);
 
     DeviceStats hs;
@@ -383,7 +414,15 @@ rt_status rt_create(rt_ctx** out, const rt_config* cfg) {
     c->device = dev;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(nullptr, RT_ERR_HIP, "hipStreamCreate failed"); }
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipEventCreateWithFlags(&c->evInit, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; ok && k < rt_ctx::kMaxSets; k++) {
+        ok = hipEventCreateWithFlags(&c->evResolve[k], hipEventDisableTiming) == hipSuccess;
+        if (ok && k > 0) ok = hipStreamCreate(&c->extra[k]) == hipSuccess;
+    }
+    if (!ok) {
+        rt_destroy(c);
+        return fail(nullptr, RT_ERR_HIP, "stream / event creation failed");
+    }
     *out = c;
     return RT_OK;
 }
@@ -391,10 +430,17 @@ rt_status rt_create(rt_ctx** out, const rt_config* cfg) {
 void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipStream_t x : c->extra) if (x) (void)hipStreamSynchronize(x);
+    for (auto& ps : c->set) {
+        DevBuf* pb[] = {&ps.rayOD, &ps.rayS, &ps.hit, &ps.shadeLoc, &ps.contrib, &ps.depth, &ps.queues, &ps.shadowQueue, &ps.counters, &ps.overflow};
+        for (DevBuf* b : pb) b->release();
+    }
+    for (hipEvent_t ev : c->evResolve) if (ev) (void)hipEventDestroy(ev);
+    if (c->evInit) (void)hipEventDestroy(c->evInit);
+    for (hipStream_t x : c->extra) if (x) (void)hipStreamDestroy(x);
     DevBuf* bufs[] = {&c->dNodes, &c->dTris, &c->dShade, &c->dMaterials, &c->dVertices, &c->dLights, &c->dTexDescs,
-                      &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->rayOD, &c->shadeLoc, &c->rayS,
-                      &c->hit, &c->contrib, &c->depth, &c->accum, &c->queues, &c->shadowQueue, &c->counters, &c->dStats, &c->overflow};
+                      &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->accum, &c->dStats};
     for (DevBuf* b : bufs) b->release();
     for (auto& t : c->textures) t.data.release();
     for (auto& e : c->evRing) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
@@ -428,6 +474,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "countVisits")) c->countVisits = v;
     else if (name_is(name, "samplesPerPass")) c->samplesPerPass = v;
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
+    else if (name_is(name, "passStreams")) c->passStreams = v < 1 ? 4 : v;      // < 1: back to the default
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
 }
 rt_status rt_set_float(rt_ctx* c, const char* name, float v) {
@@ -545,8 +592,8 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     if (!hadLights) c->slotSet[RT_SLOT_LIGHTS] = false;
     if (s) return s;
     uint32_t nslots = (uint32_t)((n + 63) / 64 * 64);
-    if ((s = ensure_paths(c, nslots, nslots, 1, 1))) return s;
-    PathBuffers P = make_paths(c, nslots, nslots, 1);
+    if ((s = ensure_paths(c, 0, nslots, nslots, 1, 1))) return s;
+    PathBuffers P = make_paths(c, 0, nslots, nslots, 1);
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;
     SceneView S = make_view(c, exact);
