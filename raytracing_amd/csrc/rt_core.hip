@@ -59,11 +59,11 @@ struct rt_ctx {
     // Up to four sets of per-pass path buffers: consecutive passes run on `passStreams` streams, so that the small, tail-dominated
     // launches of one pass's late bounces overlap the large launches of the next pass (only k_resolve is ordered).
     struct PathSet { DevBuf rayOD, rayS, hit, shadeLoc, contrib, depth, queues, shadowQueue, counters, overflow; };
-    static constexpr int kMaxSets = 4;
+    static constexpr int kMaxSets = 8;
     PathSet set[kMaxSets];
     DevBuf accum, dStats;
-    hipStream_t extra[kMaxSets] = {nullptr, nullptr, nullptr, nullptr};     // streams of sets 1.. (set 0 uses `stream`)
-    hipEvent_t evResolve[kMaxSets] = {nullptr, nullptr, nullptr, nullptr}, evInit = nullptr;
+    hipStream_t extra[kMaxSets] = {};     // streams of sets 1.. (set 0 uses `stream`)
+    hipEvent_t evResolve[kMaxSets] = {}, evInit = nullptr;
     int32_t passStreams = 4;
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
 
@@ -187,6 +187,11 @@ uint32_t overflow_depth(rt_ctx* c) {
     return (uint32_t)need;
 }
 
+void release_set(rt_ctx::PathSet& ps) {
+    DevBuf* pb[] = {&ps.rayOD, &ps.rayS, &ps.hit, &ps.shadeLoc, &ps.contrib, &ps.depth, &ps.queues, &ps.shadowQueue, &ps.counters, &ps.overflow};
+    for (DevBuf* b : pb) b->release();
+}
+
 rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
     rt_status s;
     size_t n = nslots;
@@ -265,16 +270,28 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint64_t slotBudget = 1ull << 28;   // ~210 B of path state + log per slot
     if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
     if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
-    const uint32_t nslots = S_ * sps;
     const uint32_t lightSlots = (uint32_t)std::max(1, F.numLights);
 
-    const uint32_t nPasses = (r1 - r0 + S_ - 1) / std::max(1u, S_);
-    const int nSets = (int)std::max(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t)std::max(1, (int)c->passStreams), rt_ctx::kMaxSets), nPasses));
+    // Path buffers: `passStreams` sets of S_ samples.  When the device cannot hold them (another tenant, a smaller
+    // part), fall back first to fewer streams, then to fewer samples in flight — the image does not depend on either.
+    uint32_t nslots = 0;
+    int nSets = 1;
     PathBuffers Pset[rt_ctx::kMaxSets];
-    for (int k = 0; k < nSets; k++) {
-        if ((s = ensure_paths(c, k, nslots, sps, lightSlots, maxB))) return s;
-        Pset[k] = make_paths(c, k, nslots, sps, lightSlots);
+    for (;;) {
+        nslots = S_ * sps;
+        const uint32_t nPasses = (r1 - r0 + S_ - 1) / std::max(1u, S_);
+        nSets = (int)std::max(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t)std::max(1, (int)c->passStreams), rt_ctx::kMaxSets), nPasses));
+        int got = 0;
+        for (; got < nSets; got++)
+            if ((s = ensure_paths(c, got, nslots, sps, lightSlots, maxB))) break;
+        if (got == nSets) break;
+        (void)hipGetLastError();
+        release_set(c->set[got]);
+        if (got >= 1) { nSets = got; break; }
+        if (S_ <= 1) return s;
+        S_ = std::max(1u, S_ / 2);
     }
+    for (int k = 0; k < nSets; k++) Pset[k] = make_paths(c, k, nslots, sps, lightSlots);
     PathBuffers P = Pset[0];
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;
@@ -302,7 +319,9 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     k_init_frame<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, iAlb, iNor, iDep);
 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
-    hipStream_t streams[rt_ctx::kMaxSets] = {c->stream, c->extra[1], c->extra[2], c->extra[3]};
+    hipStream_t streams[rt_ctx::kMaxSets];
+    streams[0] = c->stream;
+    for (int k = 1; k < rt_ctx::kMaxSets; k++) streams[k] = c->extra[k];
     if (nSets > 1) {
         HIPCHK(c, hipEventRecord(c->evInit, st));                 // images + accumulators initialised
         for (int k = 1; k < nSets; k++) HIPCHK(c, hipStreamWaitEvent(streams[k], c->evInit, 0));
@@ -432,10 +451,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t x : c->extra) if (x) (void)hipStreamSynchronize(x);
-    for (auto& ps : c->set) {
-        DevBuf* pb[] = {&ps.rayOD, &ps.rayS, &ps.hit, &ps.shadeLoc, &ps.contrib, &ps.depth, &ps.queues, &ps.shadowQueue, &ps.counters, &ps.overflow};
-        for (DevBuf* b : pb) b->release();
-    }
+    for (auto& ps : c->set) release_set(ps);
     for (hipEvent_t ev : c->evResolve) if (ev) (void)hipEventDestroy(ev);
     if (c->evInit) (void)hipEventDestroy(c->evInit);
     for (hipStream_t x : c->extra) if (x) (void)hipStreamDestroy(x);
