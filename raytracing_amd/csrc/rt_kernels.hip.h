@@ -894,3 +894,4 @@ __global__ __launch_bounds__(RT_BLOCK) void k_load_rays(PathBuffers P, const flo
 
 }  // namespace rt
 
+#include "rt_trace_refill.hip.h"

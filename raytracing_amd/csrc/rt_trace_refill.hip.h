@@ -1,0 +1,348 @@
+// gfx950 traversal kernels with dynamic ray fetch (traversalMode 0, knob `refill`; included by rt_kernels.hip.h).
+//
+// A wave of the batch kernels traces one fixed set of 64 rays and runs until the longest of them is done.  On a scene
+// that does not fit the caches (C4: 20 M triangles, 25 nodes per ray, dependent misses to the Infinity Cache / HBM)
+// only 13 % of the lanes are active per node step, so a wave has few misses in flight and the kernel is bound by memory
+// latency.  Here a wave is persistent instead: whenever `refillIdle` or more of its lanes have finished their ray it
+// hands those lanes new rays and goes on, which keeps more independent misses in flight per wave.  Work distribution
+// uses no atomics (one contended counter word costs ~30 ns per grab on MI355X): wave w owns the 64-ray groups
+// w, w + nWaves, w + 2 nWaves ... of the queue, so the resident waves work on one compact window of the queue and of the
+// path-state arrays.  On cache-resident scenes (C1-C3, C5) the batch kernels are faster and stay the default.
+//
+// Per-ray arithmetic: that of closest_hit<false,..,true> / occluded_fast<..,true> (shader.comp:104-125, 171-184,
+// 243-290) — same expressions, same order.  Rays that could produce a NaN in a slab test take the select-form routines
+// above, one ray at a time.
+#pragma once
+
+namespace rt {
+
+// shader.comp:104-125 on a pre-transformed triangle: true + t on a hit.
+__device__ __forceinline__ bool tri_t(float4 A, float4 B, float4 C, v3 o, v3 d, float* tOut) {
+    v3 v0 = mk(A.x, A.y, A.z), e1 = mk(A.w, B.x, B.y), e2 = mk(B.z, B.w, C.x);
+    v3 pv = cross3(d, e2);
+    float det = dot3(e1, pv);
+    if (fabsf(det) < 1e-8f) return false;
+    float invDet = 1.0f / det;
+    v3 s = o - v0;
+    float u = dot3(s, pv) * invDet;
+    if (u < 0.0f || u > 1.0f) return false;
+    v3 q = cross3(s, e1);
+    float v = dot3(d, q) * invDet;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = dot3(e2, q) * invDet;
+    if (t < 1e-8f) return false;
+    *tOut = t;
+    return true;
+}
+
+// This wave's share of the work items [0, n): the 64-item groups wave, wave + nWaves, wave + 2 nWaves ... (grid
+// stride), so the waves resident at one time work on one compact window of the queue and of the path-state arrays
+// (contiguous per-wave ranges spread ~5000 concurrent streams over HBM pages and were measured 30 % slower).
+// No atomics: a work counter shared by all waves costs ~30 ns per grab on MI355X (one L2 atomic unit serves the
+// word), which at 64..1024 items per grab was measured to cost more than the lanes it keeps busy.
+struct WavePool {
+    uint32_t next, end;      // unassigned items of the current group
+    uint32_t group, stride, n;
+    __device__ __forceinline__ void open_group() {
+        next = group < n ? group : n;
+        end = (n - next < 64u) ? n : next + 64u;
+    }
+    __device__ __forceinline__ bool empty() const { return next >= end; }
+    // after handing out items: move to the wave's next group when the current one is used up
+    __device__ __forceinline__ void take(uint32_t k) {
+        next += k;
+        if (next >= end && group < n) { group = (n - group <= stride) ? n : group + stride; open_group(); }
+    }
+};
+__device__ __forceinline__ WavePool wave_pool(uint32_t n) {
+    WavePool wp;
+    wp.n = n;
+    wp.stride = gridDim.x * RT_BLOCK;
+    wp.group = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * 64u));
+    wp.open_group();
+    return wp;
+}
+
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Closest hit == lineCast (shader.comp:243-290) for the rays of `queue` (PRIMARY: the camera rays of all slots).
+template <bool COUNT, bool PRIMARY>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
+                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count,
+                                                         int rBase, uint32_t rayCount, int refillIdle,
+                                                         DeviceStats* stats) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    const Stack stk = make_stack(lds, P);
+    const uint32_t n = *count;
+    const float INF = __int_as_float(0x7f800000);
+    WavePool wp = wave_pool(n);
+    uint32_t nNodes = 0, nTris = 0, maxSteps = 0, steps0 = 0;
+
+    bool active = false;
+    uint32_t slot = 0;
+    v3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
+    RayPairs R = make_pairs(o, o);
+    float bestT = INF, bestDist = 3.40282347e+38f, lim = INF;
+    int bestIdx = -1, bestRef = -1;
+    int sp = 0, cur = RT_DONE;
+
+    auto popNext = [&]() {
+        cur = RT_DONE;
+        while (sp > 0) {
+            uint2 e = stk.pop(sp);
+            if (__uint_as_float(e.y) > lim) continue;
+            cur = (int)e.x;
+            break;
+        }
+    };
+
+    for (;;) {
+        const unsigned long long idleMask = __ballot(!active);
+        const int nIdle = __popcll(idleMask);
+        if (!wp.empty() && nIdle >= refillIdle) {
+            {
+                const uint32_t pre = lane_prefix(idleMask);
+                const uint32_t avail = wp.end - wp.next;
+                if (!active && pre < avail) {
+                    const uint32_t i = wp.next + pre;
+                    bool ok = true;
+                    if (PRIMARY) {
+                        slot = i;
+                        int px, py, r;
+                        o = ld3(F.camPos);
+                        ok = primary_ray(F, P, rBase, slot, &px, &py, &r, &d);
+                        if (!ok) P.hit[slot] = make_float2(0.f, __int_as_float(-2));
+                    } else {
+                        slot = queue[i];
+                        uint32_t fl;
+                        load_ray(P, slot, o, d, fl);
+                    }
+                    if (ok) {
+                        if (!ray_is_plain(o, d)) {
+                            HitRec best;
+                            closest_hit<false, COUNT, false>(S, o, d, stk, best, nNodes, nTris);
+                            P.hit[slot] = make_float2(best.t, __int_as_float(best.ref));
+                        } else {
+                            v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                            float te;
+                            if (COUNT) { nNodes++; steps0 = nNodes + nTris; }
+                            if (!slab<true>(o, inv, S.rootLo, S.rootHi, &te)) {
+                                P.hit[slot] = make_float2(__int_as_float(0x7f800000), __int_as_float(-1));
+                            } else {
+                                R = make_pairs(o, inv);
+                                bestT = INF; bestDist = 3.40282347e+38f; lim = INF; bestIdx = -1; bestRef = -1;
+                                sp = 0; cur = S.rootChild;
+                                active = true;
+                            }
+                        }
+                    }
+                }
+                wp.take(((uint32_t)nIdle < avail) ? (uint32_t)nIdle : avail);
+                continue;
+            }
+        }
+        if (nIdle == 64) break;
+        const bool canRefill = !wp.empty();
+
+        for (;;) {
+            while (cur >= 0) {
+                const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+                float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                if (COUNT) nNodes++;
+                float te0, tx0, te1, tx1;
+                slab_pair(R, n0, n1, n2, te0, tx0, te1, tx1);
+                bool p0 = tx0 >= te0 && tx0 >= 0.0f && !(te0 > lim);
+                bool p1 = tx1 >= te1 && tx1 >= 0.0f && !(te1 > lim);
+                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                if (p0 && p1) {
+                    bool swap = te1 < te0;
+                    uint2 e; e.x = (uint32_t)(swap ? c0 : c1); e.y = __float_as_uint(swap ? te0 : te1);
+                    stk.push(sp, e);
+                    cur = swap ? c1 : c0;
+                } else if (p0) cur = c0;
+                else if (p1) cur = c1;
+                else popNext();
+            }
+            if (cur != RT_DONE) {      // a leaf (idle lanes sit at RT_DONE)
+                int code = -cur - 1;
+                int first = code >> 3, cnt = code & 7;
+                const float4* tp = reinterpret_cast<const float4*>(S.tris + first);
+                for (int k = 0; k < cnt; k++) {
+                    if (COUNT) nTris++;
+                    float4 A = tp[3 * k], B = tp[3 * k + 1], C = tp[3 * k + 2];
+                    float t;
+                    if (tri_t(A, B, C, o, d, &t)) {
+                        v3 h = o + d * t;
+                        v3 oh = o - h;
+                        float newDist = dot3(oh, oh);
+                        int idx = first + k;
+                        if (newDist < bestDist || (newDist == bestDist && idx < bestIdx)) {
+                            bestDist = newDist; bestT = t; bestIdx = idx; bestRef = __float_as_int(C.y);
+                            lim = bestT + bestT * 1e-4f + S.cullAbs;
+                        }
+                    }
+                }
+                popNext();
+            }
+            if (active && cur == RT_DONE) {
+                P.hit[slot] = make_float2(bestT, __int_as_float(bestRef));
+                if (COUNT) { uint32_t st = nNodes + nTris - steps0 + 1; if (st > maxSteps) maxSteps = st; }
+                active = false;
+            }
+            const unsigned long long am = __ballot(active);
+            if (am == 0ull) break;
+            if (canRefill && 64 - __popcll(am) >= refillIdle) break;
+        }
+    }
+
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(PRIMARY ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)(rayCount ? rayCount : n));
+    if (COUNT) {
+        __shared__ uint32_t red[2];
+        if (threadIdx.x < 2) red[threadIdx.x] = 0;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) { nNodes += __shfl_down(nNodes, off, 64); nTris += __shfl_down(nTris, off, 64); }
+        for (int off = 32; off > 0; off >>= 1) { uint32_t o2 = __shfl_down(maxSteps, off, 64); if (o2 > maxSteps) maxSteps = o2; }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nNodes); atomicAdd(&red[1], nTris); if (maxSteps) atomicMax(&stats->max_ray_steps, (unsigned long long)maxSteps); }
+        __syncthreads();
+        if (threadIdx.x == 0 && (red[0] | red[1])) {
+            atomicAdd(&stats->node_visits, (unsigned long long)red[0]);
+            atomicAdd(&stats->tri_tests, (unsigned long long)red[1]);
+        }
+    }
+}
+
+// shader.comp:453-484: the shadow lineCast of every log entry awaiting one; the entry becomes "add" (2) or "none" (0).
+// Work item i = (shadow-queue entry i / numLights, light i % numLights).
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
+                                                         int bounce, int refillIdle, DeviceStats* stats) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    const Stack stk = make_stack(lds, P);
+    const uint32_t L = (uint32_t)F.numLights;
+    const uint32_t n = *count * L;
+    const float INF = __int_as_float(0x7f800000);
+    WavePool wp = wave_pool(n);
+    uint32_t nNodes = 0, nTris = 0;
+
+    bool active = false, occ = false;
+    float* wptr = nullptr;
+    v3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f), shadeLoc = mk(0.f, 0.f, 0.f);
+    RayPairs R = make_pairs(o, o);
+    float distToLight = 0.f, lim = INF;
+    int kind = 1;
+    int sp = 0, cur = RT_DONE;
+
+    for (;;) {
+        const unsigned long long idleMask = __ballot(!active);
+        const int nIdle = __popcll(idleMask);
+        if (!wp.empty() && nIdle >= refillIdle) {
+            {
+                const uint32_t pre = lane_prefix(idleMask);
+                const uint32_t avail = wp.end - wp.next;
+                if (!active && pre < avail) {
+                    const uint32_t i = wp.next + pre;
+                    const uint32_t q = (L == 1u) ? i : i / L, l = (L == 1u) ? 0u : i % L;
+                    const uint32_t slot = P.shadowQueue[q];
+                    float* wp_ = &P.contrib[((size_t)bounce * P.lightSlots + l) * P.nslots + slot].w;
+                    if (*wp_ == 1.f) {
+                        float4 o4 = P.rayOD[2u * slot];
+                        o = mk(o4.x, o4.y, o4.z); shadeLoc = mk(0.f, 0.f, 0.f);
+                        if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; shadeLoc = mk(h4.x, h4.y, h4.z); }
+                        const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
+                        float4 L0 = lp[0], L1 = lp[1];
+                        kind = (int)__float_as_uint(L1.w);
+                        distToLight = 0.f;
+                        if (kind == 0) {
+                            v3 toL = mk(L0.x, L0.y, L0.z) - shadeLoc;
+                            d = normalize3(toL);
+                            distToLight = length3(toL);
+                        } else d = -mk(L1.x, L1.y, L1.z);
+                        wptr = wp_;
+                        if (!ray_is_plain(o, d)) {
+                            bool oc = occluded_fast<COUNT, false>(S, o, d, kind, shadeLoc, distToLight, stk, nNodes, nTris);
+                            *wptr = oc ? 0.f : 2.f;
+                        } else {
+                            v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                            float te;
+                            if (COUNT) nNodes++;
+                            if (!slab<true>(o, inv, S.rootLo, S.rootHi, &te)) {
+                                *wptr = 2.f;
+                            } else {
+                                R = make_pairs(o, inv);
+                                lim = (kind == 0) ? (distToLight + distToLight * 1e-3f + S.cullAbs * 4.0f) : INF;
+                                occ = false; sp = 0; cur = S.rootChild;
+                                active = true;
+                            }
+                        }
+                    }
+                }
+                wp.take(((uint32_t)nIdle < avail) ? (uint32_t)nIdle : avail);
+                continue;
+            }
+        }
+        if (nIdle == 64) break;
+        const bool canRefill = !wp.empty();
+
+        for (;;) {
+            while (cur >= 0) {
+                const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+                float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                if (COUNT) nNodes++;
+                float te0, tx0, te1, tx1;
+                slab_pair(R, n0, n1, n2, te0, tx0, te1, tx1);
+                bool p0 = tx0 >= te0 && tx0 >= 0.0f && !(te0 > lim);
+                bool p1 = tx1 >= te1 && tx1 >= 0.0f && !(te1 > lim);
+                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                if (p0 && p1) {      // nearer box first: an occluder, if any, tends to be found sooner
+                    bool swap = te1 < te0;
+                    uint2 e; e.x = (uint32_t)(swap ? c0 : c1); e.y = 0u; stk.push(sp, e);
+                    cur = swap ? c1 : c0;
+                } else if (p0) cur = c0;
+                else if (p1) cur = c1;
+                else if (sp > 0) cur = (int)stk.pop(sp).x;
+                else cur = RT_DONE;
+            }
+            if (cur != RT_DONE) {
+                int code = -cur - 1;
+                int first = code >> 3, cnt = code & 7;
+                const float4* tp = reinterpret_cast<const float4*>(S.tris + first);
+                for (int k = 0; k < cnt; k++) {
+                    if (COUNT) nTris++;
+                    float t;
+                    if (tri_t(tp[3 * k], tp[3 * k + 1], tp[3 * k + 2], o, d, &t)) {
+                        if (kind == 1) occ = true;
+                        else { v3 h = o + d * t; v3 dl = h - shadeLoc; if (sqrtf(dot3(dl, dl)) < distToLight) occ = true; }
+                    }
+                }
+                if (occ) cur = RT_DONE;
+                else if (sp > 0) cur = (int)stk.pop(sp).x;
+                else cur = RT_DONE;
+            }
+            if (active && cur == RT_DONE) {
+                *wptr = occ ? 0.f : 2.f;
+                active = false;
+            }
+            const unsigned long long am = __ballot(active);
+            if (am == 0ull) break;
+            if (canRefill && 64 - __popcll(am) >= refillIdle) break;
+        }
+    }
+
+    if (COUNT) {
+        __shared__ uint32_t red[2];
+        if (threadIdx.x < 2) red[threadIdx.x] = 0;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) { nNodes += __shfl_down(nNodes, off, 64); nTris += __shfl_down(nTris, off, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nNodes); atomicAdd(&red[1], nTris); }
+        __syncthreads();
+        if (threadIdx.x == 0 && (red[0] | red[1])) {
+            atomicAdd(&stats->shadow_node_visits, (unsigned long long)red[0]);
+            atomicAdd(&stats->shadow_tri_tests, (unsigned long long)red[1]);
+        }
+    }
+}
+
+}  // namespace rt

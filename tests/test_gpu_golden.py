@@ -12,9 +12,16 @@ pytestmark = pytest.mark.gpu
 VEC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors")
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+# every execution strategy of the core must give the same bits: culled/ordered and reference-order traversal, the
+# dynamic-fetch traversal kernels, one sample per pass on three overlapping streams, a single stream
+VARIANTS = {"culled": {"traversalMode": 0}, "reference_order": {"traversalMode": 1},
+            "dynamic_fetch": {"refill": 1, "refillIdle": 24}, "dynamic_fetch_eager": {"refill": 1, "refillIdle": 1},
+            "streams3_spp1": {"samplesPerPass": 1, "passStreams": 3}, "one_stream": {"samplesPerPass": 2, "passStreams": 1}}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("scene", [2, 3, 4, 7])
-def test_hip_path_reproduces_golden(models_root, scene, mode):
+def test_hip_path_reproduces_golden(models_root, scene, variant):
     from raytracing_amd import ComputeShader
     from raytracing_amd import scene as S
     g = np.load(os.path.join(VEC, "scene%d.npz" % scene), allow_pickle=False)
@@ -24,7 +31,8 @@ def test_hip_path_reproduces_golden(models_root, scene, mode):
     cs.resize(W, H)
     cs.setInt("samplesPerPixel", spp)
     cs.setInt("maxBounces", b)
-    cs.setInt("traversalMode", mode)
+    for k, v in VARIANTS[variant].items():
+        cs.setInt(k, v)
     S.set_camera(cs, S.DEFAULT_CAMERA[0], S.DEFAULT_CAMERA[1], W, H, 45.0)
     cs.dispatch()
     for k, name in enumerate(("color", "albedo", "normal", "depth")):
