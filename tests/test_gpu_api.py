@@ -202,3 +202,27 @@ def test_camera_path_driver_writes_reference_frames(oracle_lib, models_root, tmp
         want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, camera=cam, math_mode=1))["color"]
         ref8 = (np.nan_to_num(np.clip(want[::-1, :, :3], 0, 1), nan=0.0) * np.float32(255)).astype(np.uint8)
         assert np.array_equal(got, ref8), f
+
+
+def test_cpp_example_renders_the_reference_frames(oracle_lib, models_root, tmp_path):
+    """examples/headless_main.cpp (CMake build, C++ host classes with the reference's names over the C ABI): the offline
+    render writes frame 0 with the default camera and the following frames on the orbit, as Renderer.cpp does."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "headless_main")
+    if not os.path.exists(exe):
+        pytest.skip("build/headless_main is not built (cmake -S . -B build -G Ninja && cmake --build build)")
+    W, H, spp, b = 64, 36, 2, 4
+    out = subprocess.run([exe, models_root, "4", str(W), str(H), str(spp), str(b), "2", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = tmp_path / ("Scene-4_spp-%d_bounces-%d" % (spp, b))
+    sc = oracle_lib.load_scene(models_root, 4)
+    raw = (d / "frame_0000.ppm").read_bytes()
+    hdr = b"P6\n%d %d\n255\n" % (W, H)
+    assert raw.startswith(hdr)
+    got = np.frombuffer(raw[len(hdr):], np.uint8).reshape(H, W, 3)
+    want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))["color"]
+    ref8 = (np.nan_to_num(np.clip(want[::-1, :, :3], 0, 1), nan=0.0) * np.float32(255)).astype(np.uint8)
+    assert np.array_equal(got, ref8)
+    assert (d / "frame_0001.ppm").exists()

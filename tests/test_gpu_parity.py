@@ -146,3 +146,35 @@ def test_million_random_rays_both_modes(scenes):
         assert m.sum() > n // 100
         assert np.array_equal(bits(h0)[m], bits(h1)[m])
         cs.Delete()
+
+
+@pytest.mark.parametrize("knobs", [{}, {"refill": 1}, {"refill": 1, "refillIdle": 1, "refillBlocksPerCU": 1}, {"traversalMode": 1}])
+def test_synthetic_height_field_bit_exact(oracle_lib, tmp_path, knobs):
+    """Config 4's generator at a size the oracle finishes in seconds (2 x 150^2 = 45 000 triangles, tree depth > the
+    8 LDS stack entries, centroid ties): the same GLTF through the product's loader/builder/kernels and through the
+    oracle, all four images bit for bit — batch kernels, dynamic-fetch kernels (also with one resident workgroup per CU
+    and eager refill) and the reference-order traversal."""
+    from oracle import gltf_flatten as G
+    from raytracing_amd import ComputeShader, synthetic
+    from raytracing_amd import scene as S
+    path = str(tmp_path / "hf")
+    synthetic.write_gltf(path, 150)
+    flat = G.flatten([path + ".gltf"])
+    flat["lights"], flat["hasSun"] = G.lights_to_gpu(synthetic.SYNTHETIC_LIGHTS)
+    sc = oracle_lib.Scene(flat)
+    W, H, spp, b = 96, 56, 3, 5
+    want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
+    cs = ComputeShader()
+    S.Scene.LoadModels(cs, [path + ".gltf"], synthetic.SYNTHETIC_LIGHTS)
+    cs.resize(W, H)
+    cs.setInt("samplesPerPixel", spp)
+    cs.setInt("maxBounces", b)
+    for k, v in knobs.items():
+        cs.setInt(k, v)
+    S.set_camera(cs, S.DEFAULT_CAMERA[0], S.DEFAULT_CAMERA[1], W, H, 45.0)
+    cs.dispatch()
+    for k, name in enumerate(("color", "albedo", "normal", "depth")):
+        assert same_floats(cs.get_image(k), want[name]).all(), name
+    tri, _ = cs.primary_hits()
+    assert np.array_equal(tri, want["prim_tri"])
+    cs.Delete()
