@@ -64,7 +64,7 @@ struct rt_ctx {
     DevBuf accum, dStats;
     hipStream_t extra[kMaxSets] = {};     // streams of sets 1.. (set 0 uses `stream`)
     hipEvent_t evResolve[kMaxSets] = {}, evInit = nullptr;
-    int32_t passStreams = 4;
+    int32_t passStreams = 4, autoPass = 1;
     // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill -1 = automatic (on when the compact BVH is far
     // larger than the L2s, where traversal is bound by miss latency; measured +14 % on the 20 M-triangle config,
     // -15 % on the cache-resident ones), 0 = off, 1 = on
@@ -279,6 +279,12 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint64_t slotBudget = 1ull << 28;   // ~210 B of path state + log per slot
     if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
     if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
+    // A short sample range (one rank's share of a frame split over several GPUs) is cut into at least `passStreams`
+    // passes of >= 16 samples, so that the passes still overlap on the streams.
+    if (c->autoPass != 0 && c->passStreams > 1) {
+        const uint32_t want = (r1 - r0 + (uint32_t)c->passStreams - 1) / (uint32_t)c->passStreams;
+        if (want < S_) S_ = std::max<uint32_t>(std::min<uint32_t>(16u, S_), want);
+    }
     const uint32_t lightSlots = (uint32_t)std::max(1, F.numLights);
 
     // Path buffers: `passStreams` sets of S_ samples.  When the device cannot hold them (another tenant, a smaller
@@ -515,6 +521,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
     else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 1 ? 1 : v;
+    else if (name_is(name, "autoPass")) c->autoPass = v;
     else if (name_is(name, "passStreams")) c->passStreams = v < 1 ? 4 : v;      // < 1: back to the default
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
 }
