@@ -10,7 +10,8 @@
 //   k_resolve           shader.comp:332,521   replays the log into the pixel colour in the reference's order
 //                                              (sample, bounce, light), so float sums are bit-identical to the serial shader
 //   k_finalize          shader.comp:533-536   image stores
-// Compaction between stages: wave64 ballot + mbcnt prefix, one atomic per wave.
+// Compaction between stages: wave64 ballot + mbcnt prefix, wave totals through LDS, one atomic per queue per 1024 paths.
+// Consecutive passes run on several streams with their own PathBuffers (rt_core.hip); only k_resolve is ordered.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
