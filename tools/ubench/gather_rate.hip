@@ -10,6 +10,8 @@
 
 // MODE 0: 4 x dwordx4 from one 64-B record per lane (a node fetch)   MODE 1: 1 x dwordx4   MODE 2: 1 x dword
 // MODE 3: 4 x ds_read_b128 from an LDS copy (64-B records)           MODE 4: 2 x dwordx4 (32-B record)
+// MODE 7: 4 x dwordx4, the 4 lanes of a quad reading the 4 words of one 64-B record (coalesced 64-B requests)
+// MODE 5: 8 x dwordx4 from one 128-B record per lane (a whole cache line: a 4-wide node)   MODE 6: 3 x dwordx4 at 48-B stride (a triangle record)
 template <int MODE>
 __global__ __launch_bounds__(256) void k(const float4* __restrict__ table, uint32_t nrec, int iters, int activeLanes, int uniform, float* out) {
     __shared__ float4 lds[MODE == 3 ? 2048 * 4 : 1];
@@ -28,6 +30,13 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ table, uint3
             else if (MODE == 2) { acc += reinterpret_cast<const float*>(table)[(size_t)r * 16]; }
             else if (MODE == 3) { const float4* p = lds + r * 4; a = p[0]; b = p[1]; c = p[2]; d = p[3]; acc += a.x + b.y + c.z + d.w; }
             else if (MODE == 4) { const float4* p = table + (size_t)r * 4; a = p[0]; b = p[1]; acc += a.x + b.y; }
+            else if (MODE == 5) { const float4* p = table + (size_t)(r >> 1) * 8; a = p[0]; b = p[1]; c = p[2]; d = p[3]; float4 e = p[4], f = p[5], g = p[6], h = p[7]; acc += a.x + b.y + c.z + d.w + e.x + f.y + g.z + h.w; }
+            else if (MODE == 7) {   // quad-cooperative: the 4 lanes of a quad fetch the four 16-B words of ONE 64-B record per instruction
+                uint32_t q = lane & 3u;
+                uint32_t r0 = __shfl(r, (lane & ~3u) + 0, 64), r1 = __shfl(r, (lane & ~3u) + 1, 64), r2 = __shfl(r, (lane & ~3u) + 2, 64), r3 = __shfl(r, (lane & ~3u) + 3, 64);
+                a = table[(size_t)r0 * 4 + q]; b = table[(size_t)r1 * 4 + q]; c = table[(size_t)r2 * 4 + q]; d = table[(size_t)r3 * 4 + q];
+                acc += a.x + b.y + c.z + d.w; }
+            else if (MODE == 6) { const float4* p = table + (size_t)r * 3; a = p[0]; b = p[1]; c = p[2]; acc += a.x + b.y + c.z; }
             // dependent chain like a traversal: next index depends on the data
             x += (uint32_t)(acc != 12345.678f);
         }
@@ -65,6 +74,9 @@ int main() {
     run<4>("2 x global_load_dwordx4", table, nrec, out, 2);
     run<1>("1 x global_load_dwordx4", table, nrec, out, 1);
     run<2>("1 x global_load_dword", table, nrec, out, 1);
+    run<5>("8 x dwordx4 (128-B record)", table, nrec, out, 8);
+    run<6>("3 x dwordx4 (48-B stride)", table, nrec, out, 3);
+    run<7>("4 x dwordx4 quad-cooperative", table, nrec, out, 4);
     run<3>("4 x ds_read_b128", table, nrec, out, 4);
     return 0;
 }
