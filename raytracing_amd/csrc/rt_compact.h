@@ -18,6 +18,7 @@ struct CompactScene {
     std::vector<CNode> nodes;
     std::vector<CTri> tris;
     std::vector<CShade> shade;
+    std::vector<CShadeUV> shadeUV;
     int32_t rootChild = -1;
     float rootLo[3] = {0, 0, 0}, rootHi[3] = {0, 0, 0};
     float sceneScale = 1.f;
@@ -43,6 +44,7 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
     // ---- per-triangle world-space vertices + shading records ----
     std::vector<f3> wv(nTris * 3);
     out.shade.resize(nTris);
+    out.shadeUV.resize(nTris);
     for (uint64_t i = 0; i < nTris; i++) {
         const RefTriangle& t = rtris[i];
         for (int k = 0; k < 3; k++)
@@ -52,10 +54,13 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
         const RefMat4& M = mats[t.meshIndex];
         for (int k = 0; k < 3; k++) wv[i * 3 + k] = mul_point(M, verts[t.indices[k]].position, 1.f);
         CShade& s = out.shade[i];
+        CShadeUV& su = out.shadeUV[i];
+        std::memset(&su, 0, sizeof su);
+        s.pad = 0;
         const f3 P[3] = {t.p1, t.p2, t.p3};
         float* dstP[3] = {s.a, s.b, s.c};
         float* dstN[3] = {s.n1, s.n2, s.n3};
-        float* dstUV[3] = {s.uv1, s.uv2, s.uv3};
+        float* dstUV[3] = {su.uv1, su.uv2, su.uv3};
         for (int k = 0; k < 3; k++) {
             dstP[k][0] = P[k].x; dstP[k][1] = P[k].y; dstP[k][2] = P[k].z;
             f3 n = mul_point(M, verts[t.indices[k]].normal, 0.f);
@@ -63,7 +68,7 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
             dstUV[k][0] = verts[t.indices[k]].texUV[0]; dstUV[k][1] = verts[t.indices[k]].texUV[1];
         }
         s.materialIndex = t.materialIndex;
-        s.i1 = t.indices[0]; s.i2 = t.indices[1]; s.i3 = t.indices[2];
+        su.i1 = t.indices[0]; su.i2 = t.indices[1]; su.i3 = t.indices[2];
     }
 
     // ---- scene scale (for the slack terms of traversalMode 0) ----

@@ -44,7 +44,7 @@ struct rt_ctx {
     int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64;
 
     // device scene
-    DevBuf dNodes, dTris, dShade, dMaterials, dVertices, dLights, dTexDescs;
+    DevBuf dNodes, dTris, dShade, dShadeUV, dMaterials, dCMat, dVertices, dLights, dTexDescs;
     std::vector<Texture> textures;
     CompactScene cs;
     uint64_t nLights = 0, nMaterials = 0;
@@ -122,6 +122,7 @@ rt_status sync_scene(rt_ctx* c) {
         if ((s = upload(c, c->dNodes, c->cs.nodes.data(), c->cs.nodes.size() * sizeof(CNode)))) return s;
         if ((s = upload(c, c->dTris, c->cs.tris.data(), c->cs.tris.size() * sizeof(CTri)))) return s;
         if ((s = upload(c, c->dShade, c->cs.shade.data(), c->cs.shade.size() * sizeof(CShade)))) return s;
+        if ((s = upload(c, c->dShadeUV, c->cs.shadeUV.data(), c->cs.shadeUV.size() * sizeof(CShadeUV)))) return s;
         if ((s = upload(c, c->dVertices, V.data(), V.size()))) return s;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->sceneDirty = false;
@@ -139,6 +140,15 @@ rt_status sync_scene(rt_ctx* c) {
         rt_status s = upload(c, c->dMaterials, M.data(), M.size());
         if (s) return s;
         c->nMaterials = M.size() / 80;
+        std::vector<CMat> cm(c->nMaterials);
+        for (size_t i = 0; i < cm.size(); i++) {
+            const RefMaterial* m = (const RefMaterial*)M.data() + i;
+            for (int k = 0; k < 3; k++) cm[i].baseColor[k] = m->baseColorFactor[k];
+            cm[i].transmission = m->transmissionFactor; cm[i].metallic = m->metallicFactor; cm[i].roughness = m->roughnessFactor;
+            cm[i].ior = m->ior;
+            cm[i].flags = (m->hasBaseTexture == 1 ? 1u : 0u) | (m->hasNormalTexture == 1 ? 2u : 0u) | (m->hasMetallicRoughnessTexture == 1 ? 4u : 0u);
+        }
+        if ((s = upload(c, c->dCMat, cm.data(), cm.size() * sizeof(CMat)))) return s;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->materialsDirty = false;
     }
@@ -165,6 +175,7 @@ SceneView make_view(rt_ctx* c, bool exact) {
     SceneView S;
     std::memset(&S, 0, sizeof S);
     S.nodes = (const CNode*)c->dNodes.p; S.tris = (const CTri*)c->dTris.p; S.shade = (const CShade*)c->dShade.p;
+    S.shadeUV = (const CShadeUV*)c->dShadeUV.p; S.cmat = (const CMat*)c->dCMat.p;
     S.materials = (const RefMaterial*)c->dMaterials.p; S.vertices = (const RefVertex*)c->dVertices.p;
     S.lights = (const RefLight*)c->dLights.p; S.textures = (const TexDesc*)c->dTexDescs.p;
     S.n_textures = (uint32_t)c->textures.size();
@@ -264,6 +275,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     F.numLights = c->numLights < 0 ? 0 : c->numLights; F.hasSun = c->hasSun;
     for (int l = 0; l < F.numLights && (size_t)(l + 1) * 48 <= c->slotHost[RT_SLOT_LIGHTS].size(); l++)
         if (((const RefLight*)c->slotHost[RT_SLOT_LIGHTS].data())[l].lightType == 0u) F.anyPoint = 1;
+    std::memcpy(F.lights, c->slotHost[RT_SLOT_LIGHTS].data(), std::min<size_t>(sizeof F.lights, c->slotHost[RT_SLOT_LIGHTS].size()));
     for (int k = 0; k < 3; k++) { F.camPos[k] = c->camPos[k]; F.camForward[k] = c->camForward[k]; F.camRight[k] = c->camRight[k]; F.camUp[k] = c->camUp[k]; }
     F.aspect = c->aspect;
     F.tanHalfFov = tanf((c->fov * 0.017453292519943295f) / 2.0f);   // tan(radians(fov) / 2.0), shader.comp:321
@@ -483,7 +495,7 @@ void rt_destroy(rt_ctx* c) {
     for (hipEvent_t ev : c->evResolve) if (ev) (void)hipEventDestroy(ev);
     if (c->evInit) (void)hipEventDestroy(c->evInit);
     for (hipStream_t x : c->extra) if (x) (void)hipStreamDestroy(x);
-    DevBuf* bufs[] = {&c->dNodes, &c->dTris, &c->dShade, &c->dMaterials, &c->dVertices, &c->dLights, &c->dTexDescs,
+    DevBuf* bufs[] = {&c->dNodes, &c->dTris, &c->dShade, &c->dShadeUV, &c->dCMat, &c->dMaterials, &c->dVertices, &c->dLights, &c->dTexDescs,
                       &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->accum, &c->dStats};
     for (DevBuf* b : bufs) b->release();
     for (auto& t : c->textures) t.data.release();

@@ -573,7 +573,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
             int ref = __float_as_int(h2.y);
             v3 camPos = ld3(F.camPos);
             float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;   // entry of light l at logp[l * nslots]
-            P.depth[slot] = ref == -2 ? 0u : (uint32_t)bounce + 1u;
             if (ref == -2) {
                 // dead slot (edge tile outside the region)
             } else if (ref < 0) {
@@ -586,11 +585,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
             } else {
                 v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122)
                 const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
-                float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4], q5 = sp[5], q6 = sp[6];
+                float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4];
                 v3 a = mk(q0.x, q0.y, q0.z), b = mk(q0.w, q1.x, q1.y), c = mk(q1.z, q1.w, q2.x);
                 v3 n1 = mk(q2.y, q2.z, q2.w), n2 = mk(q3.x, q3.y, q3.z), n3 = mk(q3.w, q4.x, q4.y);
-                float uv1x = q4.z, uv1y = q4.w, uv2x = q5.x, uv2y = q5.y, uv3x = q5.z, uv3y = q5.w;
-                uint32_t matIdx = __float_as_uint(q6.x);
+                uint32_t matIdx = __float_as_uint(q4.z);
+                const float4* m4 = reinterpret_cast<const float4*>(S.cmat + matIdx);
+                float4 m0 = m4[0], m1 = m4[1];
+                const uint32_t mflags = __float_as_uint(m1.w);
+                const bool hasBase = (mflags & 1u) != 0u, hasNormal = (mflags & 2u) != 0u, hasMR = (mflags & 4u) != 0u;
+                float uv1x = 0.f, uv1y = 0.f, uv2x = 0.f, uv2y = 0.f, uv3x = 0.f, uv3y = 0.f;
+                float4 q6 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mflags != 0u) {          // UVs and vertex ids only matter to textured / normal-mapped materials
+                    const float4* up = reinterpret_cast<const float4*>(S.shadeUV + ref);
+                    float4 u0 = up[0], u1 = up[1], u2 = up[2];
+                    uv1x = u0.x; uv1y = u0.y; uv2x = u0.z; uv2y = u0.w; uv3x = u1.x; uv3y = u1.y;
+                    q6 = make_float4(0.f, u1.z, u1.w, u2.x);
+                }
                 // barycentric, shader.comp:132-151
                 v3 v0 = b - a, v1 = c - a, v2 = hitLoc - a;
                 float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
@@ -601,18 +611,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 v3 hitNormal = (n1 * bu + n2 * bv + n3 * bw);
                 float hitU = uv1x * bu + uv2x * bv + uv3x * bw;
                 float hitV = uv1y * bu + uv2y * bv + uv3y * bw;
-                const RefMaterial* mp = S.materials + matIdx;
-                const float4* m4 = reinterpret_cast<const float4*>(mp);
-                float4 m0 = m4[0], m1 = m4[1], m2 = m4[2], m3 = m4[3], m4v = m4[4];
-                int hasBase = __float_as_int(m1.z), hasNormal = __float_as_int(m2.z), hasMR = __float_as_int(m3.z);
-                float transmission = m1.w, ior = m4v.x;
+                const RefMaterial* mp = S.materials + matIdx;        // texture handles (read only under a flag)
+                float transmission = m0.w, ior = m1.z;
                 float metallicFactor, roughnessFactor;
-                if (hasMR == 1) {
+                if (hasMR) {
                     float4 t = sample_tex(S, mp->metallicRoughnessTexture, hitU, hitV);
                     metallicFactor = t.x; roughnessFactor = t.y;
-                } else { metallicFactor = m2.w; roughnessFactor = m3.w; }
+                } else { metallicFactor = m1.x; roughnessFactor = m1.y; }
                 v3 normal;
-                if (hasNormal == 1) {
+                if (hasNormal) {
                     uint32_t i1 = __float_as_uint(q6.y), i2 = __float_as_uint(q6.z), i3 = __float_as_uint(q6.w);
                     const float* t1 = S.vertices[i1].tangent; const float* t2 = S.vertices[i2].tangent; const float* t3 = S.vertices[i3].tangent;
                     v3 tangent = (ld3(t1) * bu + ld3(t2) * bv + ld3(t3) * bw);
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
 
                 // lighting set-up, shader.comp:433-451
                 v3 baseColor = mk(m0.x, m0.y, m0.z);
-                if (hasBase == 1) {
+                if (hasBase) {
                     float4 t = sample_tex(S, mp->baseColorTexture, hitU, hitV);
                     baseColor = mk(t.x, t.y, t.z);
                 }
@@ -697,8 +704,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 // light loop, shader.comp:453-522 minus the shadow lineCast (k_shadow)
                 if (F.numLights == 0) logp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int l = 0; l < F.numLights; l++) {
-                    const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
-                    float4 L0 = lp[0], L1 = lp[1], L2 = lp[2];
+                    const RefLight& Lg = F.lights[l];      // kernarg, uniform index: scalar loads
+                    float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, __uint_as_float(Lg.lightType)), L2 = make_float4(Lg.color.x, Lg.color.y, Lg.color.z, 0.f);
                     uint32_t ltype = __float_as_uint(L1.w);
                     v3 dirToLight = mk(0.f, 0.f, 0.f);
                     float attenuation = 1.f;
@@ -749,6 +756,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 if (cont) P.rayS[slot] = make_float4(strength.x, strength.y, strength.z, 0.f);
                 if (wantShadow && F.anyPoint) P.shadeLoc[slot] = make_float4(hitLoc.x, hitLoc.y, hitLoc.z, 0.f);
             }
+            // bounces shaded by this slot's path: written once, by the bounce at which the path ends
+            if (!cont) P.depth[slot] = ref == -2 ? 0u : (uint32_t)bounce + 1u;
         }
         contMask |= (cont ? 1u : 0u) << item;
         shadowMask |= (wantShadow ? 1u : 0u) << item;
@@ -797,9 +806,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
         for (int l = 0; l < F.numLights; l++) {
             float* wp = &logp[(size_t)l * P.nslots].w;
             if (*wp != 1.f) continue;
-            const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
-            float4 L0 = lp[0], L1 = lp[1];
-            uint32_t ltype = __float_as_uint(L1.w);
+            const RefLight& Lg = F.lights[l];      // kernarg, uniform index: scalar loads
+            float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, 0.f);
+            uint32_t ltype = Lg.lightType;
             v3 dirToLight; float distToLight = 0.f;
             if (ltype == 0u) {
                 v3 toL = mk(L0.x, L0.y, L0.z) - hitLoc;

@@ -81,16 +81,31 @@ struct CTri {
 };
 static_assert(sizeof(CTri) == 48, "CTri");
 
-// Shading inputs per reference triangle (indexed by refIndex): everything shader.comp:342-357 fetches
-// through Triangle / Vertex / meshProj, resolved once at upload.
-struct CShade {
+// Shading inputs per reference triangle (indexed by refIndex): everything shader.comp:342-357 fetches through
+// Triangle / Vertex / meshProj, resolved once at upload.  Split by use — k_shade is bound by the number of
+// per-lane load instructions, and only textured / normal-mapped materials need the second record.
+struct CShade {                    // 80 B = 5 x dwordx4
     float a[3], b[3], c[3];        // Triangle.p1..p3 (mesh-local, used by barycentric())
     float n1[3], n2[3], n3[3];     // vec3(meshProj * vec4(normal, 0))
-    float uv1[2], uv2[2], uv3[2];
     uint32_t materialIndex;
-    uint32_t i1, i2, i3;           // vertex ids (tangent fetch for normal-mapped materials)
+    uint32_t pad;
 };
-static_assert(sizeof(CShade) == 112, "CShade");
+static_assert(sizeof(CShade) == 80, "CShade");
+struct CShadeUV {                  // 48 B, fetched only when the material samples a texture
+    float uv1[2], uv2[2], uv3[2];
+    uint32_t i1, i2, i3;           // vertex ids (tangent fetch for normal-mapped materials)
+    uint32_t pad[3];
+};
+static_assert(sizeof(CShadeUV) == 48, "CShadeUV");
+
+// The scalars of MaterialData the integrator reads on every hit (model.h:8-39), 2 x dwordx4 instead of 5; texture
+// handles stay in the reference record (slot 2), read only when a flag says so.
+struct CMat {
+    float baseColor[3]; float transmission;
+    float metallic, roughness, ior;
+    uint32_t flags;                // bit0 hasBaseTexture == 1, bit1 hasNormalTexture == 1, bit2 hasMetallicRoughnessTexture == 1
+};
+static_assert(sizeof(CMat) == 32, "CMat");
 
 struct TexDesc { const uint8_t* rgba8; uint32_t width, height; };
 
@@ -104,6 +119,8 @@ struct SceneView {
     const CNode* nodes;
     const CTri* tris;
     const CShade* shade;
+    const CShadeUV* shadeUV;
+    const CMat* cmat;
     const RefMaterial* materials;
     const RefVertex* vertices;
     const RefLight* lights;
@@ -121,6 +138,7 @@ struct FrameParams {
     int32_t tilesX;                // region width in 8x8 tiles
     int32_t numLights, hasSun;
     int32_t anyPoint;              // a point light is among the numLights lights (k_shadow then needs the shade location)
+    RefLight lights[RT_MAX_LIGHTS];  // slot 5, by value: kernels that index it uniformly read it with scalar loads
     float camPos[3], camForward[3], camRight[3], camUp[3];
     float aspect, tanHalfFov;
     int32_t samplesPerPixel, maxBounces;
