@@ -805,7 +805,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
         float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;
         for (int l = 0; l < F.numLights; l++) {
             float* wp = &logp[(size_t)l * P.nslots].w;
-            if (*wp != 1.f) continue;
+            if (F.numLights > 1 && *wp != 1.f) continue;     // (one light: a queued slot always awaits its shadow ray)
             const RefLight& Lg = F.lights[l];      // kernarg, uniform index: scalar loads
             float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, 0.f);
             uint32_t ltype = Lg.lightType;

@@ -12,6 +12,7 @@ S.Scene.LoadScene(cs, 4, models)
 cs.resize(W, H); cs.setInt("samplesPerPixel", spp); cs.setInt("maxBounces", 8)
 S.set_camera(cs, S.DEFAULT_CAMERA[0], S.DEFAULT_CAMERA[1], W, H, 45.0)
 cs.dispatch_region(0, 0, W, H, 0, 64)
+t1 = 1.0
 for n in (1, 2, 4, 8, 16):
     for sp in (0, 64, 32, 16):
         cs.setInt("samplesPerPass", sp if sp else 64)
@@ -22,4 +23,6 @@ for n in (1, 2, 4, 8, 16):
         for _ in range(2):
             cs.dispatch_region(0, 0, W, H, 0, r1)
         dt = (time.perf_counter() - t) / 2
-        print("N=%2d samples %4d samplesPerPass %s: %7.2f ms  -> %5.1f%% of ideal (N=1 time / N)" % (n, r1, sp if sp else "auto", dt * 1e3, 0), flush=True)
+        if n == 1 and sp == 0:
+            t1 = dt
+        print("N=%2d samples %4d samplesPerPass %4s: %7.2f ms  (ideal %.2f ms = frame / N: %5.1f %%)" % (n, r1, sp if sp else "auto", dt * 1e3, t1 * 1e3 / n, 100 * t1 / n / dt), flush=True)

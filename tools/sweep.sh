@@ -5,7 +5,7 @@ COMMON=()
 while [ "$1" != "--" ]; do COMMON+=("$1"); shift; done
 shift
 IFS=';' read -ra VARS <<< "$*"
-: > "$OUT"
+mkdir -p "$(dirname "$OUT")"; : > "$OUT"
 for v in "${VARS[@]}"; do
   echo "== $v" >> "$OUT"
   timeout -k 10 300 python bench.py "${COMMON[@]}" $v --no-cpu-baseline 2>&1 | python -c "
