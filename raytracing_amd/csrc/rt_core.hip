@@ -58,7 +58,7 @@ struct rt_ctx {
     // path state
     // Up to four sets of per-pass path buffers: consecutive passes run on `passStreams` streams, so that the small, tail-dominated
     // launches of one pass's late bounces overlap the large launches of the next pass (only k_resolve is ordered).
-    struct PathSet { DevBuf rayOD, rayS, hit, shadeLoc, contrib, depth, queues, shadowQueue, counters, overflow; };
+    struct PathSet { DevBuf ray[2], rayS[2], hit, shadowRec, shadeLoc, contrib, depth, counters, overflow; };
     static constexpr int kMaxSets = 8;
     PathSet set[kMaxSets];
     DevBuf accum, dStats;
@@ -208,7 +208,7 @@ uint32_t overflow_depth(rt_ctx* c) {
 }
 
 void release_set(rt_ctx::PathSet& ps) {
-    DevBuf* pb[] = {&ps.rayOD, &ps.rayS, &ps.hit, &ps.shadeLoc, &ps.contrib, &ps.depth, &ps.queues, &ps.shadowQueue, &ps.counters, &ps.overflow};
+    DevBuf* pb[] = {&ps.ray[0], &ps.ray[1], &ps.rayS[0], &ps.rayS[1], &ps.hit, &ps.shadowRec, &ps.shadeLoc, &ps.contrib, &ps.depth, &ps.counters, &ps.overflow};
     for (DevBuf* b : pb) b->release();
 }
 
@@ -217,15 +217,16 @@ rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
     size_t n = nslots;
     rt_ctx::PathSet& ps = c->set[which];
     if ((s = ensure(c, ps.overflow, (size_t)overflow_depth(c) * trace_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
-    if ((s = ensure(c, ps.rayOD, n * 32))) return s;
+    for (int k = 0; k < 2; k++) {
+        if ((s = ensure(c, ps.ray[k], n * 32))) return s;
+        if ((s = ensure(c, ps.rayS[k], n * 16))) return s;
+    }
+    if ((s = ensure(c, ps.shadowRec, n * 16))) return s;
     if ((s = ensure(c, ps.shadeLoc, n * 16))) return s;
-    if ((s = ensure(c, ps.rayS, n * 16))) return s;
     if ((s = ensure(c, ps.hit, n * 8))) return s;
     if ((s = ensure(c, ps.contrib, n * 16 * lightSlots * std::max<uint32_t>(1, maxBounces)))) return s;
     if ((s = ensure(c, ps.depth, n * 4))) return s;
     if ((s = ensure(c, c->accum, (size_t)slotsPerSample * 16))) return s;
-    if ((s = ensure(c, ps.queues, n * 4 * 2))) return s;
-    if ((s = ensure(c, ps.shadowQueue, n * 4))) return s;
     if ((s = ensure(c, ps.counters, (size_t)(2 * (maxBounces + 1)) * 4))) return s;
     if ((s = ensure(c, c->dStats, sizeof(DeviceStats)))) return s;
     return RT_OK;
@@ -234,9 +235,10 @@ rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
 PathBuffers make_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots) {
     PathBuffers P;
     rt_ctx::PathSet& ps = c->set[which];
-    P.rayOD = (float4*)ps.rayOD.p; P.rayS = (float4*)ps.rayS.p; P.hit = (float2*)ps.hit.p; P.shadeLoc = (float4*)ps.shadeLoc.p;
+    for (int k = 0; k < 2; k++) { P.ray[k] = (float4*)ps.ray[k].p; P.rayS[k] = (float4*)ps.rayS[k].p; }
+    P.hit = (float2*)ps.hit.p; P.shadowRec = (float4*)ps.shadowRec.p; P.shadeLoc = (float4*)ps.shadeLoc.p;
     P.contrib = (float4*)ps.contrib.p; P.depth = (uint32_t*)ps.depth.p; P.accum = (float4*)c->accum.p;
-    P.queues = (uint32_t*)ps.queues.p; P.shadowQueue = (uint32_t*)ps.shadowQueue.p; P.counters = (uint32_t*)ps.counters.p;
+    P.counters = (uint32_t*)ps.counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots;
     P.overflow = (uint2*)ps.overflow.p; P.overflowStride = trace_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
@@ -399,19 +401,18 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         HIPCHK(c, hipMemsetAsync(P.counters, 0, (size_t)(2 * (maxB + 1)) * 4, st));
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)qcount, (int)Pp.nslots, 1, st));   // bounce 0: every slot carries a path
         for (uint32_t b = 0; b < maxB; b++) {
-            uint32_t* qin = b == 0 ? nullptr : P.queues + (size_t)(b & 1) * nslots;   // bounce 0: identity queue
-            uint32_t* qout = P.queues + (size_t)((b + 1) & 1) * nslots;
+            const float4* qin = b == 0 ? nullptr : P.ray[b & 1];       // bounce 0: entry i is slot i, camera rays are regenerated
             rt_ctx::EvPair* e = evBegin(0);
             if (refill && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
                 const dim3 rg(refill_blocks(c, Pp.nslots));
-                if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
-                else k_extend_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
+                if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
+                else k_extend_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
             }
-            else if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
-            else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
+            else if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const float4*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
+            else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
             evEnd(e);
             e = evBegin(1);
-            k_shade<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)qin, (const uint32_t*)(qcount + b), qout, qcount + b + 1,
+            k_shade<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(qcount + b), qcount + b + 1,
                                               scount + b, (int)rBase, (int)b, iAlb, iNor, iDep, pTri, pHit, dst);
             evEnd(e);
             if (F.numLights > 0) {
@@ -664,10 +665,10 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     DeviceStats* dst = (DeviceStats*)c->dStats.p;
     (void)hipMemsetAsync(dst, 0, sizeof(DeviceStats), st);
     uint32_t blocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
-    k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, (const float*)dO.p, (const float*)dD.p, (uint32_t)n, P.queues, P.counters);
+    k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, (const float*)dO.p, (const float*)dD.p, (uint32_t)n, P.counters);
     FrameParams F0;
     std::memset(&F0, 0, sizeof F0);
-    launch_extend<false>(exact, count, dim3(trace_blocks(c, nslots)), st, S, F0, P, (const uint32_t*)P.queues,
+    launch_extend<false>(exact, count, dim3(trace_blocks(c, nslots)), st, S, F0, P, (const float4*)P.ray[0],
                              (const uint32_t*)P.counters, 0, 0u, dst);
     hipError_t e = hipStreamSynchronize(st);
     std::vector<float> h2(n * 2);

@@ -23,16 +23,19 @@ namespace rt {
 #define RT_BLOCK 256
 
 struct PathBuffers {
-    // Path state is laid out by 32-byte sectors, the unit the CU's vector-memory path charges for:
-    float4* rayOD;       // [2*slot] = (o.xyz, d.x), [2*slot+1] = (d.y, d.z, flag bits (bit0 refracting), 0): one sector per ray
-    float4* rayS;        // strength.xyz
-    float2* hit;         // (t, reference triangle index bits: -1 miss, -2 dead slot); hitLoc = o + d * t is recomputed
-    float4* shadeLoc;    // hitLoc of the bounce being shaded, written only when a point light needs it (k_shadow)
+    // Per-path state lives at the path's POSITION IN ITS BOUNCE'S QUEUE, not at its slot: a bounce's kernels then read
+    // and write it with dense, coalesced accesses instead of gathers through a queue of slot ids (the scattered
+    // 16-byte accesses into multi-GB arrays were HBM round trips on every ray).  Two buffers alternate by bounce parity.
+    float4* ray[2];      // entry i: [2i] = (o.xyz, d.x), [2i+1] = (d.y, d.z, flag bits (bit0 refracting), slot bits)
+    float4* rayS[2];     // entry i: strength.xyz
+    float2* hit;         // entry i of the bounce being traced: (t, reference triangle index bits: -1 miss, -2 dead slot);
+                         // hitLoc = o + d * t is recomputed by k_shade
+    float4* shadowRec;   // shadow-queue entry j: (origin.xyz, slot bits)
+    float4* shadeLoc;    // [slot] hitLoc of the bounce being shaded, written only when a point light needs it (k_shadow)
+    // Indexed by slot (= sampleInPass * slotsPerSample + tileSlot), because k_resolve replays them per pixel:
     float4* contrib;     // contribution log [maxBounces][lightSlots][nslots]: rgb, w = 0 none / 1 awaiting shadow ray / 2 add
-    uint32_t* depth;     // [nslots] bounces shaded so far by the slot's path (log entries [0, depth) are valid)
-    float4* accum;       // [slotsPerSample] running pixel colour (the shader's `color`), survives passes
-    uint32_t* queues;    // [2][nslots]
-    uint32_t* shadowQueue;
+    uint32_t* depth;     // [nslots] bounces shaded by the slot's path (log entries [0, depth) are valid)
+    float4* accum;       // [slotsPerSample] running pixel colour (the shader's `color`), survives passes, shared by all sets
     uint32_t* counters;  // [0..maxB] path-queue sizes per bounce, [maxB+1 .. 2maxB+1] shadow-queue sizes
     uint2* overflow;     // traversal-stack entries beyond the LDS part: entry k of thread g at overflow[k*overflowStride + g]
     uint32_t overflowStride, overflowDepth;
@@ -40,13 +43,8 @@ struct PathBuffers {
     uint32_t slotsPerSample, lightSlots;   // lightSlots = max(1, numLights)
 };
 
-__device__ __forceinline__ void load_ray(const PathBuffers& P, uint32_t slot, v3& o, v3& d, uint32_t& flags) {
-    float4 a = P.rayOD[2u * slot], b = P.rayOD[2u * slot + 1u];
-    o = mk(a.x, a.y, a.z); d = mk(a.w, b.x, b.y); flags = __float_as_uint(b.z);
-}
-__device__ __forceinline__ void store_ray(const PathBuffers& P, uint32_t slot, v3 o, v3 d, uint32_t flags) {
-    P.rayOD[2u * slot] = make_float4(o.x, o.y, o.z, d.x);
-    P.rayOD[2u * slot + 1u] = make_float4(d.y, d.z, __uint_as_float(flags), 0.f);
+__device__ __forceinline__ void unpack_ray(float4 a, float4 b, v3& o, v3& d, uint32_t& flags, uint32_t& slot) {
+    o = mk(a.x, a.y, a.z); d = mk(a.w, b.x, b.y); flags = __float_as_uint(b.z); slot = __float_as_uint(b.w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,10 +406,10 @@ __device__ __forceinline__ bool primary_ray(const FrameParams& F, const PathBuff
     return px < F.rx + F.rw && py < F.ry + F.rh;
 }
 
-// queue == nullptr: identity (bounce 0).  rayCount > 0 overrides the number of rays added to the counters
+// rays: the bounce's ray buffer (PRIMARY: unused, entry i is slot i).  rayCount > 0 overrides the number of rays added to the counters
 // (bounce 0: region pixels, not slots).
 template <bool EXACT, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F, PathBuffers P, const float4* __restrict__ rays,
                                                      const uint32_t* __restrict__ count, int rBase, uint32_t rayCount,
                                                      DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
@@ -420,24 +418,21 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F,
     uint32_t nNodes = 0, nTris = 0, maxSteps = 0;
     uint32_t wSteps[2] = {0u, 0u};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
-        uint32_t slot;
         v3 ro, rd;
         if (PRIMARY) {
-            slot = i;
             int px, py, r;
             ro = ld3(F.camPos);
-            if (!primary_ray(F, P, rBase, slot, &px, &py, &r, &rd)) { P.hit[slot] = make_float2(0.f, __int_as_float(-2)); continue; }
+            if (!primary_ray(F, P, rBase, i, &px, &py, &r, &rd)) { P.hit[i] = make_float2(0.f, __int_as_float(-2)); continue; }
         } else {
-            slot = queue[i];
-            uint32_t fl;
-            load_ray(P, slot, ro, rd, fl);
+            uint32_t fl, slot;
+            unpack_ray(rays[2u * i], rays[2u * i + 1u], ro, rd, fl, slot);
         }
         HitRec best;
         uint32_t before = nNodes + nTris;
         if (__all(ray_is_plain(ro, rd))) closest_hit<EXACT, COUNT, true>(S, ro, rd, stk, best, nNodes, nTris, wSteps);
         else closest_hit<EXACT, COUNT, false>(S, ro, rd, stk, best, nNodes, nTris, wSteps);
         if (COUNT) { uint32_t steps = nNodes + nTris - before; if (steps > maxSteps) maxSteps = steps; }
-        P.hit[slot] = make_float2(best.t, __int_as_float(best.ref));
+        P.hit[i] = make_float2(best.t, __int_as_float(best.ref));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(PRIMARY ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)(rayCount ? rayCount : n));
@@ -518,40 +513,40 @@ __device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float a
 
 // shader.comp:329-452 and 524-531 for one path; light loop body 486-521 is evaluated here and its
 // result parked in `pend` until k_shadow has traced the shadow ray (453-484).
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ queue,
-                                                    const uint32_t* __restrict__ count, uint32_t* queueOut, uint32_t* countOut,
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, PathBuffers P,
+                                                    const uint32_t* __restrict__ count, uint32_t* countOut,
                                                     uint32_t* shadowCountOut, int rBase, int bounce,
                                                     float4* imgAlbedo, float4* imgNormal, float4* imgDepth,
                                                     int32_t* primTri, float* primHit, DeviceStats* stats) {
     __shared__ uint32_t ldsAppend[16];
     __shared__ uint32_t ldsCount[2];
+    // The outgoing ray of an item waits here until the block knows the item's position in the next queue
+    // (entry k of thread t at [k * RT_BLOCK + t]: written and read back by the same thread, no barrier needed).
+    __shared__ float4 stageA[RT_ITEMS * RT_BLOCK], stageB[RT_ITEMS * RT_BLOCK], stageS[RT_ITEMS * RT_BLOCK];
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
+    const float4* __restrict__ raysIn = P.ray[bounce & 1];
+    const float4* __restrict__ raySIn = P.rayS[bounce & 1];
+    float4* __restrict__ raysOut = P.ray[(bounce + 1) & 1];
+    float4* __restrict__ raySOut = P.rayS[(bounce + 1) & 1];
     uint32_t n = *count;
     const uint32_t chunk = RT_BLOCK * RT_ITEMS;
     uint32_t nChunks = (n + chunk - 1) / chunk;
     uint32_t skipped = 0, pending = 0;
     for (uint32_t ch = blockIdx.x; ch < nChunks; ch += gridDim.x) {
       uint32_t contMask = 0, shadowMask = 0;
-      // The chain queue -> slot -> hit -> shading record -> material is four dependent round trips per path and this
-      // kernel has few waves to hide them (125 VGPRs), so the first two levels are taken off it: the four queue
-      // entries of this thread are fetched together, and the hit record of item k + 1 while item k is shaded.
-      static_assert(RT_ITEMS == 4, "slot prefetch below is written for 4 items");
+      // hit -> shading record -> material is a chain of dependent round trips per path and this kernel has few waves
+      // to hide them (139 VGPRs): the hit record of item k + 1 is fetched while item k is shaded.
       const uint32_t iBase = ch * chunk + threadIdx.x;
-      uint32_t q0 = iBase, q1 = iBase + RT_BLOCK, q2 = iBase + 2 * RT_BLOCK, q3 = iBase + 3 * RT_BLOCK;
-      if (queue) {
-          q0 = q0 < n ? queue[q0] : 0u; q1 = q1 < n ? queue[q1] : 0u; q2 = q2 < n ? queue[q2] : 0u; q3 = q3 < n ? queue[q3] : 0u;
-      }
-      auto slotOf = [&](int k) { return k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3; };
       float2 nextHit = make_float2(0.f, 0.f);
-      if (iBase < n) nextHit = P.hit[q0];
+      if (iBase < n) nextHit = P.hit[iBase];
 #pragma unroll 1
       for (int item = 0; item < RT_ITEMS; item++) {
         uint32_t i = iBase + (uint32_t)item * RT_BLOCK;
         bool live = i < n;
         bool cont = false, wantShadow = false;
-        uint32_t slot = slotOf(item);
+        uint32_t slot = i;                                       // bounce 0: entry i is slot i
         const float2 h2 = nextHit;
-        if (item + 1 < RT_ITEMS && i + RT_BLOCK < n) nextHit = P.hit[slotOf(item + 1)];
+        if (item + 1 < RT_ITEMS && i + RT_BLOCK < n) nextHit = P.hit[i + RT_BLOCK];
         if (live) {
             v3 rayLoc, rayDir, strength;
             bool refracting = false;
@@ -562,9 +557,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 rayLoc = ld3(F.camPos);
                 strength = mk(F.initialStrength, F.initialStrength, F.initialStrength);
             } else {
-                float4 s4 = P.rayS[slot];
+                float4 s4 = raySIn[i];
                 uint32_t fl;
-                load_ray(P, slot, rayLoc, rayDir, fl);
+                unpack_ray(raysIn[2u * i], raysIn[2u * i + 1u], rayLoc, rayDir, fl, slot);
                 strength = mk(s4.x, s4.y, s4.z);
                 refracting = (fl & RT_FLAG_REFRACTING) != 0u;
                 r = rBase + (int)(slot / P.slotsPerSample);
@@ -752,8 +747,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                     strength = strength * mk(gclamp(baseColor.x, 0.f, 1.f), gclamp(baseColor.y, 0.f, 1.f), gclamp(baseColor.z, 0.f, 1.f));
                 bool active = !(length3(strength) < F.strengthCutoff);
                 cont = active && (bounce + 1 < F.maxBounces);
-                if (cont || wantShadow) store_ray(P, slot, rayLoc, rayDir, refracting ? RT_FLAG_REFRACTING : 0u);
-                if (cont) P.rayS[slot] = make_float4(strength.x, strength.y, strength.z, 0.f);
+                if (cont || wantShadow) {
+                    const uint32_t st = (uint32_t)item * RT_BLOCK + threadIdx.x;
+                    stageA[st] = make_float4(rayLoc.x, rayLoc.y, rayLoc.z, rayDir.x);
+                    stageB[st] = make_float4(rayDir.y, rayDir.z, __uint_as_float(refracting ? RT_FLAG_REFRACTING : 0u), __uint_as_float(slot));
+                    if (cont) stageS[st] = make_float4(strength.x, strength.y, strength.z, 0.f);
+                }
                 if (wantShadow && F.anyPoint) P.shadeLoc[slot] = make_float4(hitLoc.x, hitLoc.y, hitLoc.z, 0.f);
             }
             // bounces shaded by this slot's path: written once, by the bounce at which the path ends
@@ -772,9 +771,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
 #pragma unroll
       for (int k = 0; k < RT_ITEMS; k++) {
           if (flag[0][k] | flag[1][k]) {
-              uint32_t slot = slotOf(k);
-              if (flag[0][k]) queueOut[idx[0][k]] = slot;
-              if (flag[1][k]) P.shadowQueue[idx[1][k]] = slot;
+              const uint32_t st = (uint32_t)k * RT_BLOCK + threadIdx.x;
+              const float4 a = stageA[st], b = stageB[st];
+              if (flag[0][k]) {
+                  const uint32_t o = idx[0][k];
+                  raysOut[2u * o] = a; raysOut[2u * o + 1u] = b; raySOut[o] = stageS[st];
+              }
+              if (flag[1][k]) P.shadowRec[idx[1][k]] = make_float4(a.x, a.y, a.z, b.w);
           }
       }
     }
@@ -798,8 +801,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
     uint32_t n = *count;
     uint32_t nNodes = 0, nTris = 0;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
-        uint32_t slot = P.shadowQueue[i];
-        float4 o4 = P.rayOD[2u * slot];
+        const float4 o4 = P.shadowRec[i];
+        const uint32_t slot = __float_as_uint(o4.w);
         v3 o = mk(o4.x, o4.y, o4.z), hitLoc = mk(0.f, 0.f, 0.f);
         if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; hitLoc = mk(h4.x, h4.y, h4.z); }
         float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;
@@ -891,13 +894,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_finalize(FrameParams F, PathBuffer
     }
 }
 
-// rt_trace_rays: scatter caller rays into slots 0..n-1.
-__global__ __launch_bounds__(RT_BLOCK) void k_load_rays(PathBuffers P, const float* origins, const float* dirs, uint32_t n,
-                                                        uint32_t* queueOut, uint32_t* countOut) {
+// rt_trace_rays: caller rays become entries 0..n-1 of the parity-0 ray buffer.
+__global__ __launch_bounds__(RT_BLOCK) void k_load_rays(PathBuffers P, const float* origins, const float* dirs, uint32_t n, uint32_t* countOut) {
     uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i < n) {
-        store_ray(P, i, mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), 0u);
-        queueOut[i] = i;
+        P.ray[0][2u * i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], dirs[3 * i]);
+        P.ray[0][2u * i + 1u] = make_float4(dirs[3 * i + 1], dirs[3 * i + 2], 0.f, __uint_as_float(i));
     }
     if (i == 0) *countOut = n;
 }

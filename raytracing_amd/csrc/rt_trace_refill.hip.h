@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
 // Closest hit == lineCast (shader.comp:243-290) for the rays of `queue` (PRIMARY: the camera rays of all slots).
 template <bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
-                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count,
+                                                         const float4* __restrict__ rays, const uint32_t* __restrict__ count,
                                                          int rBase, uint32_t rayCount, int refillIdle,
                                                          DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FramePa
                         ok = primary_ray(F, P, rBase, slot, &px, &py, &r, &d);
                         if (!ok) P.hit[slot] = make_float2(0.f, __int_as_float(-2));
                     } else {
-                        slot = queue[i];
-                        uint32_t fl;
-                        load_ray(P, slot, o, d, fl);
+                        slot = i;                 // entry index: where the hit record goes
+                        uint32_t fl, pathSlot;
+                        unpack_ray(rays[2u * i], rays[2u * i + 1u], o, d, fl, pathSlot);
                     }
                     if (ok) {
                         if (!ray_is_plain(o, d)) {
@@ -245,11 +245,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                 if (!active && pre < avail) {
                     const uint32_t i = wp.next + pre;
                     const uint32_t q = (L == 1u) ? i : i / L, l = (L == 1u) ? 0u : i % L;
-                    const uint32_t slot = P.shadowQueue[q];
+                    const float4 rec = P.shadowRec[q];
+                    const uint32_t slot = __float_as_uint(rec.w);
                     float* wp_ = &P.contrib[((size_t)bounce * P.lightSlots + l) * P.nslots + slot].w;
                     if (*wp_ == 1.f) {
-                        float4 o4 = P.rayOD[2u * slot];
-                        o = mk(o4.x, o4.y, o4.z); shadeLoc = mk(0.f, 0.f, 0.f);
+                        o = mk(rec.x, rec.y, rec.z); shadeLoc = mk(0.f, 0.f, 0.f);
                         if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; shadeLoc = mk(h4.x, h4.y, h4.z); }
                         const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
                         float4 L0 = lp[0], L1 = lp[1];
