@@ -75,6 +75,7 @@ struct rt_ctx {
     std::vector<EvPair> evRing;
     rt_stats stats{};
     int numCUs = 256;
+    uint64_t deviceBytes = 288ull << 30;
 };
 
 namespace {
@@ -290,8 +291,14 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     // kernels, bounded by a slot budget.
     const uint32_t maxB = (uint32_t)c->maxBounces;
     uint32_t S_ = (uint32_t)(c->samplesPerPass < 1 ? 1 : c->samplesPerPass);
-    const uint64_t slotBudget = 1ull << 28;   // ~210 B of path state + log per slot
-    if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
+    // Slot budget: all `passStreams` buffer sets together may take half of the device's memory (the scene, the
+    // images and other tenants keep the rest), and a set at most 2^28 slots.
+    {
+        const uint64_t bytesPerSlot = 2 * 32 + 2 * 16 + 8 + 16 + 16 + 4 + 16ull * (uint64_t)std::max(1, F.numLights) * std::max<uint32_t>(1, maxB);
+        const uint64_t wantSets = (uint64_t)std::min<int>(std::max(1, (int)c->passStreams), rt_ctx::kMaxSets);
+        uint64_t slotBudget = std::min<uint64_t>(1ull << 28, (c->deviceBytes / 2) / (wantSets * bytesPerSlot));
+        if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
+    }
     if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
     // A short sample range (one rank's share of a frame split over several GPUs) is cut into at least `passStreams`
     // passes of >= 16 samples, so that the passes still overlap on the streams.
@@ -473,7 +480,7 @@ rt_status rt_create(rt_ctx** out, const rt_config* cfg) {
     rt_ctx* c = new rt_ctx();
     c->device = dev;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; if (prop.totalGlobalMem) c->deviceBytes = prop.totalGlobalMem; }
     bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipEventCreateWithFlags(&c->evInit, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; ok && k < rt_ctx::kMaxSets; k++) {
         ok = hipEventCreateWithFlags(&c->evResolve[k], hipEventDisableTiming) == hipSuccess;
