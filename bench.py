@@ -163,6 +163,7 @@ def main():
         cs.dispatch_region(0, 0, W, H, r0, r1)       # returns with the images complete
         if world > 1:
             dist.reduce(color, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()                 # the reduce runs on the process group's stream; the next frame clears `color`
         return cs.stats()
 
     cs.setInt("timeKernels", 0 if args.no_kernel_timing else 1)     # HIP events around every kernel, on the launch stream, live in the timed region

@@ -42,6 +42,11 @@ def reduce_color(color_tensor, dst=0):
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(color_tensor, dst=dst, op=dist.ReduceOp.SUM)
+        if color_tensor.is_cuda:
+            # The collective runs on the process group's own stream and the core renders on its own streams: wait
+            # here, or the next frame's clear of this image would race with the reduce still reading / writing it.
+            import torch
+            torch.cuda.synchronize(color_tensor.device)
     return color_tensor
 
 
