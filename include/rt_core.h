@@ -73,7 +73,7 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * Extension names (no reference counterpart): traversalMode (0 = culled/ordered, 1 = reference-order
  * exhaustive), timeKernels (1 = HIP-event timing per kernel class into rt_stats), countVisits (1 = run the
  * instrumented traversal kernels that count node visits / triangle tests), samplesPerPass (samples of a pixel
- * traced concurrently; results do not depend on it), blocksPerCU (persistent grid size), passStreams (1..4: consecutive
+ * traced concurrently; results do not depend on it), blocksPerCU (persistent grid size), passStreams (1..8, default 4: consecutive
  * passes of samplesPerPass samples run on that many HIP streams with their own path buffers and overlap; the per-pixel
  * sum is still replayed in sample order, so results do not depend on it), refill (-1 automatic / 0 / 1: persistent
  * traversal waves that hand finished lanes new rays; automatic = on for BVHs far larger than the L2s), refillIdle,

@@ -734,8 +734,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                         v3 diffuse = diffuseColor / PI;
                         v3 radiance = mk(L2.x, L2.y, L2.z) * attenuation;
                         v3 contrib = (diffuse + specular) * radiance * NdotL * strength;
-                        pendOut = make_float4(contrib.x, contrib.y, contrib.z, cast ? 1.f : 2.f);
-                        if (cast) { wantShadow = true; pending++; }
+                        // A contribution of exactly +-0 in all three channels (mirror metals: diffuse 0 and D = 0) leaves
+                        // the pixel sum unchanged bit for bit whether or not it is added (the sum starts at +0 and
+                        // x + (+-0) == x), so the shadow ray that would decide it is not traced.  NaN fails the test.
+                        const bool nothing = cast && contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f;
+                        if (nothing) skipped++;
+                        else {
+                            pendOut = make_float4(contrib.x, contrib.y, contrib.z, cast ? 1.f : 2.f);
+                            if (cast) { wantShadow = true; pending++; }
+                        }
                         // cast == false: a light type the shader does not know gets no shadow test and its
                         // contribution (only reachable with a NaN normal) is added directly: w = 2
                     } else if (cast) skipped++;
