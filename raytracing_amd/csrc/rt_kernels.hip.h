@@ -537,16 +537,32 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
       // hit -> shading record -> material is a chain of dependent round trips per path and this kernel has few waves
       // to hide them (139 VGPRs): the hit record of item k + 1 is fetched while item k is shaded.
       const uint32_t iBase = ch * chunk + threadIdx.x;
-      float2 nextHit = make_float2(0.f, 0.f);
-      if (iBase < n) nextHit = P.hit[iBase];
+      const float2 noHit = make_float2(0.f, __int_as_float(-2));
+      float2 hq0 = noHit, hq1 = noHit, hq2 = noHit, hq3 = noHit;
+      if (iBase < n) hq0 = P.hit[iBase];
+      if (iBase + RT_BLOCK < n) hq1 = P.hit[iBase + RT_BLOCK];
+      if (iBase + 2 * RT_BLOCK < n) hq2 = P.hit[iBase + 2 * RT_BLOCK];
+      if (iBase + 3 * RT_BLOCK < n) hq3 = P.hit[iBase + 3 * RT_BLOCK];
+      static_assert(RT_ITEMS == 4, "hit-record queue below holds four items");
+      float4 nq0, nq1, nq2, nq3, nq4;
+      nq0 = nq1 = nq2 = nq3 = nq4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (__float_as_int(hq0.y) >= 0) {
+          const float4* sp = reinterpret_cast<const float4*>(S.shade + __float_as_int(hq0.y));
+          nq0 = sp[0]; nq1 = sp[1]; nq2 = sp[2]; nq3 = sp[3]; nq4 = sp[4];
+      }
 #pragma unroll 1
       for (int item = 0; item < RT_ITEMS; item++) {
         uint32_t i = iBase + (uint32_t)item * RT_BLOCK;
         bool live = i < n;
         bool cont = false, wantShadow = false;
         uint32_t slot = i;                                       // bounce 0: entry i is slot i
-        const float2 h2 = nextHit;
-        if (item + 1 < RT_ITEMS && i + RT_BLOCK < n) nextHit = P.hit[i + RT_BLOCK];
+        const float2 h2 = hq0;
+        const float4 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3, q4 = nq4;
+        hq0 = hq1; hq1 = hq2; hq2 = hq3; hq3 = noHit;
+        if (__float_as_int(hq0.y) >= 0) {                        // shading record of the next item, in flight while this one is shaded
+            const float4* sp = reinterpret_cast<const float4*>(S.shade + __float_as_int(hq0.y));
+            nq0 = sp[0]; nq1 = sp[1]; nq2 = sp[2]; nq3 = sp[3]; nq4 = sp[4];
+        }
         if (live) {
             v3 rayLoc, rayDir, strength;
             bool refracting = false;
@@ -579,8 +595,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 if (r == 0 && bounce == 0 && primTri) primTri[(size_t)py * F.width + px] = -1;
             } else {
                 v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122)
-                const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
-                float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4];
                 v3 a = mk(q0.x, q0.y, q0.z), b = mk(q0.w, q1.x, q1.y), c = mk(q1.z, q1.w, q2.x);
                 v3 n1 = mk(q2.y, q2.z, q2.w), n2 = mk(q3.x, q3.y, q3.z), n3 = mk(q3.w, q4.x, q4.y);
                 uint32_t matIdx = __float_as_uint(q4.z);
@@ -661,9 +675,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                     }
                 }
                 if (shouldReflect) {
-                    float h1 = hash13(mk((float)px, (float)py, rb) * rayDir + rayLoc);
-                    float h2 = hash13(mk((float)px * 37.f, (float)py * 37.f, rb * 37.f) * rayDir + rayLoc);
-                    v3 H = sample_ggx(normal, h1, h2, roughnessFactor);
+                    v3 H = normal;                       // sampleGGX returns N for alpha == 0 (shader.comp:194): no hashes needed
+                    if (roughnessFactor != 0.f) {
+                        float h1 = hash13(mk((float)px, (float)py, rb) * rayDir + rayLoc);
+                        float h2 = hash13(mk((float)px * 37.f, (float)py * 37.f, rb * 37.f) * rayDir + rayLoc);
+                        H = sample_ggx(normal, h1, h2, roughnessFactor);
+                    }
                     rayDir = reflect3(rayDir, H);
                     rayLoc = hitLoc + (normal * 1e-5f);
                 }
