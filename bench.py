@@ -32,6 +32,8 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 S_NODE, S_TRI = 64, 48         # bytes per compact node / triangle record
+CU_CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock
+VMEM_LANE_LOADS_PER_CLK = 1.43 # 1 / 0.7 CU-cycles per active lane and load instruction (tools/ubench/gather_rate.hip)
 
 
 def parse():
@@ -247,8 +249,20 @@ def main():
                     "kernel_ms_per_step": {k: round(agg[k] / args.steps, 2) for k in ("ms_extend", "ms_shade", "ms_shadow")},
                     "note": "bundled scenes are cache-resident (<= 13 MB): there the binding limit is the CU vector-memory/VALU path and "
                             "the HBM fraction is the contract's sanity figure (BASELINE.md); c4 is the HBM-bound configuration"}
+        # The limit that binds a cache-resident scene: per-lane load instructions through the CU's
+        # vector-memory path.  tools/ubench/gather_rate.hip measures 0.7 CU-cycles per active lane and load
+        # instruction for random gathers of L2-resident records (>= 16 active lanes) = 1.43 lane-loads per CU-clock.
+        lane_loads_per_ray = (4 * c["node_visits"] + 3 * c["tri_tests"]) / max(1, ext_rays_c)   # 64-B node = 4 x dwordx4, 48-B triangle = 3 loads
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        ext_s = ex["ms_extend"] * 1e-3
+        ll_rate = lane_loads_per_ray * ex_rays / (ext_s * cus * CU_CLOCK_HZ) if ext_s > 0 else 0.0
+        roofline["vmem_path"] = {"achieved": round(ll_rate, 3), "peak": VMEM_LANE_LOADS_PER_CLK, "unit": "lane-loads per CU-clock",
+                                 "frac": round(ll_rate / VMEM_LANE_LOADS_PER_CLK, 3), "lane_loads_per_ray": round(lane_loads_per_ray, 1),
+                                 "cus": cus, "clock_hz": CU_CLOCK_HZ,
+                                 "note": "k_extend, exclusive frame; peak = random-gather rate of tools/ubench/gather_rate.hip at the "
+                                         "nominal 2.4 GHz (coherent camera rays coalesce and run above the per-lane random rate)"}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             try:
                 cpu = cpu_baseline(args, None)
             except Exception as e:  # the baseline is reporting only; never fail the bench on it
