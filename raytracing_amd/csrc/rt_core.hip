@@ -69,6 +69,7 @@ struct rt_ctx {
     // larger than the L2s, where traversal is bound by miss latency; measured +14 % on the 20 M-triangle config,
     // -15 % on the cache-resident ones), 0 = off, 1 = on
     int32_t refill = -1, refillIdle = 8, refillBlocksPerCU = 16;
+    bool anyTextured = true, anyTransmissive = true;   // which k_shade variant the scene needs (set with the materials)
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
 
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; bool used = false; };
@@ -142,12 +143,15 @@ rt_status sync_scene(rt_ctx* c) {
         if (s) return s;
         c->nMaterials = M.size() / 80;
         std::vector<CMat> cm(c->nMaterials);
+        c->anyTextured = c->anyTransmissive = false;
         for (size_t i = 0; i < cm.size(); i++) {
             const RefMaterial* m = (const RefMaterial*)M.data() + i;
             for (int k = 0; k < 3; k++) cm[i].baseColor[k] = m->baseColorFactor[k];
             cm[i].transmission = m->transmissionFactor; cm[i].metallic = m->metallicFactor; cm[i].roughness = m->roughnessFactor;
             cm[i].ior = m->ior;
             cm[i].flags = (m->hasBaseTexture == 1 ? 1u : 0u) | (m->hasNormalTexture == 1 ? 2u : 0u) | (m->hasMetallicRoughnessTexture == 1 ? 4u : 0u);
+            if (cm[i].flags) c->anyTextured = true;
+            if (m->transmissionFactor > 0) c->anyTransmissive = true;      // the shader's own test (shader.comp:391); NaN is not > 0
         }
         if ((s = upload(c, c->dCMat, cm.data(), cm.size() * sizeof(CMat)))) return s;
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -419,8 +423,12 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
             evEnd(e);
             e = evBegin(1);
-            k_shade<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(qcount + b), qcount + b + 1,
-                                              scount + b, (int)rBase, (int)b, iAlb, iNor, iDep, pTri, pHit, dst);
+            {
+                auto shadeK = c->anyTextured ? k_shade<true, true>
+                                             : (c->anyTransmissive ? k_shade<false, true> : k_shade<false, false>);
+                shadeK<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(qcount + b), qcount + b + 1,
+                                                 scount + b, (int)rBase, (int)b, iAlb, iNor, iDep, pTri, pHit, dst);
+            }
             evEnd(e);
             if (F.numLights > 0) {
                 e = evBegin(2);

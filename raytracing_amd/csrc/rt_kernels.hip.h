@@ -513,6 +513,9 @@ __device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float a
 
 // shader.comp:329-452 and 524-531 for one path; light loop body 486-521 is evaluated here and its
 // result parked in `pend` until k_shadow has traced the shadow ray (453-484).
+// TEX / GLASS: the scene has a textured (or normal-mapped) material / a transmissive one.  Scenes without them run a
+// variant with those branches compiled out: fewer live registers on the common path.
+template <bool TEX, bool GLASS>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, PathBuffers P,
                                                     const uint32_t* __restrict__ count, uint32_t* countOut,
                                                     uint32_t* shadowCountOut, int rBase, int bounce,
@@ -522,7 +525,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
     __shared__ uint32_t ldsCount[2];
     // The outgoing ray of an item waits here until the block knows the item's position in the next queue
     // (entry k of thread t at [k * RT_BLOCK + t]: written and read back by the same thread, no barrier needed).
-    __shared__ float4 stageA[RT_ITEMS * RT_BLOCK], stageB[RT_ITEMS * RT_BLOCK], stageS[RT_ITEMS * RT_BLOCK];
+    // 36 bytes per item: (o.xyz, d.x) (d.y, d.z, s.x, s.y) (s.z); slot and flag stay in registers.
+    __shared__ float4 stageA[RT_ITEMS * RT_BLOCK], stageB[RT_ITEMS * RT_BLOCK];
+    __shared__ float stageC[RT_ITEMS * RT_BLOCK];
+    // PF: the chunk's four hit records are fetched up front (hit -> shading record -> material is a chain of dependent
+    // round trips).  8 registers; the variants without textures still fit 128 (4 waves per SIMD) with it.  Fetching the
+    // next item's shading record or ray state ahead as well costs a wave per SIMD and is slower (measured).
+    constexpr bool PF = true;
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
     const float4* __restrict__ raysIn = P.ray[bounce & 1];
     const float4* __restrict__ raySIn = P.rayS[bounce & 1];
@@ -533,22 +542,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
     uint32_t nChunks = (n + chunk - 1) / chunk;
     uint32_t skipped = 0, pending = 0;
     for (uint32_t ch = blockIdx.x; ch < nChunks; ch += gridDim.x) {
-      uint32_t contMask = 0, shadowMask = 0;
-      // hit -> shading record -> material is a chain of dependent round trips per path and this kernel has few waves
-      // to hide them (139 VGPRs): the hit record of item k + 1 is fetched while item k is shaded.
+      uint32_t contMask = 0, shadowMask = 0, refrMask = 0;
+      uint32_t slotK[RT_ITEMS] = {0u, 0u, 0u, 0u};
       const uint32_t iBase = ch * chunk + threadIdx.x;
       const float2 noHit = make_float2(0.f, __int_as_float(-2));
       float2 hq0 = noHit, hq1 = noHit, hq2 = noHit, hq3 = noHit;
-      if (iBase < n) hq0 = P.hit[iBase];
-      if (iBase + RT_BLOCK < n) hq1 = P.hit[iBase + RT_BLOCK];
-      if (iBase + 2 * RT_BLOCK < n) hq2 = P.hit[iBase + 2 * RT_BLOCK];
-      if (iBase + 3 * RT_BLOCK < n) hq3 = P.hit[iBase + 3 * RT_BLOCK];
       static_assert(RT_ITEMS == 4, "hit-record queue below holds four items");
-      float4 nq0, nq1, nq2, nq3, nq4;
-      nq0 = nq1 = nq2 = nq3 = nq4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (__float_as_int(hq0.y) >= 0) {
-          const float4* sp = reinterpret_cast<const float4*>(S.shade + __float_as_int(hq0.y));
-          nq0 = sp[0]; nq1 = sp[1]; nq2 = sp[2]; nq3 = sp[3]; nq4 = sp[4];
+      if (PF) {
+          if (iBase < n) hq0 = P.hit[iBase];
+          if (iBase + RT_BLOCK < n) hq1 = P.hit[iBase + RT_BLOCK];
+          if (iBase + 2 * RT_BLOCK < n) hq2 = P.hit[iBase + 2 * RT_BLOCK];
+          if (iBase + 3 * RT_BLOCK < n) hq3 = P.hit[iBase + 3 * RT_BLOCK];
       }
 #pragma unroll 1
       for (int item = 0; item < RT_ITEMS; item++) {
@@ -556,13 +560,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
         bool live = i < n;
         bool cont = false, wantShadow = false;
         uint32_t slot = i;                                       // bounce 0: entry i is slot i
-        const float2 h2 = hq0;
-        const float4 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3, q4 = nq4;
-        hq0 = hq1; hq1 = hq2; hq2 = hq3; hq3 = noHit;
-        if (__float_as_int(hq0.y) >= 0) {                        // shading record of the next item, in flight while this one is shaded
-            const float4* sp = reinterpret_cast<const float4*>(S.shade + __float_as_int(hq0.y));
-            nq0 = sp[0]; nq1 = sp[1]; nq2 = sp[2]; nq3 = sp[3]; nq4 = sp[4];
-        }
+        float2 h2 = hq0;
+        if (PF) { hq0 = hq1; hq1 = hq2; hq2 = hq3; hq3 = noHit; }
+        else if (live) h2 = P.hit[i];
         if (live) {
             v3 rayLoc, rayDir, strength;
             bool refracting = false;
@@ -595,12 +595,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 if (r == 0 && bounce == 0 && primTri) primTri[(size_t)py * F.width + px] = -1;
             } else {
                 v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122)
+                const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
+                const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4];
                 v3 a = mk(q0.x, q0.y, q0.z), b = mk(q0.w, q1.x, q1.y), c = mk(q1.z, q1.w, q2.x);
                 v3 n1 = mk(q2.y, q2.z, q2.w), n2 = mk(q3.x, q3.y, q3.z), n3 = mk(q3.w, q4.x, q4.y);
                 uint32_t matIdx = __float_as_uint(q4.z);
                 const float4* m4 = reinterpret_cast<const float4*>(S.cmat + matIdx);
                 float4 m0 = m4[0], m1 = m4[1];
-                const uint32_t mflags = __float_as_uint(m1.w);
+                const uint32_t mflags = TEX ? __float_as_uint(m1.w) : 0u;
                 const bool hasBase = (mflags & 1u) != 0u, hasNormal = (mflags & 2u) != 0u, hasMR = (mflags & 4u) != 0u;
                 float uv1x = 0.f, uv1y = 0.f, uv2x = 0.f, uv2y = 0.f, uv3x = 0.f, uv3y = 0.f;
                 float4 q6 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 // reflect / refract, shader.comp:389-431
                 bool shouldReflect = true;
                 float rb = (float)(r * bounce);
-                if (transmission > 0) {
+                if (GLASS && transmission > 0) {
                     float iorAir = 1.f;
                     float cosi = gclamp(dot3(-rayDir, normal), -1.0f, 1.0f);
                     float r0 = (iorAir - ior) / (iorAir + ior);
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 }
                 v3 viewDir = normalize3(camPos - hitLoc);
                 float dielectricF0 = .04f;
-                if (transmission > 0) { float e = (ior - 1.0f) / (ior + 1.0f); dielectricF0 = e * e; }
+                if (GLASS && transmission > 0) { float e = (ior - 1.0f) / (ior + 1.0f); dielectricF0 = e * e; }
                 v3 F0 = mk(dielectricF0, dielectricF0, dielectricF0) * (1.0f - metallicFactor) + baseColor * metallicFactor;
                 float alpha = roughnessFactor * roughnessFactor;
                 const float PI = 3.14159265359f;
@@ -774,8 +776,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 if (cont || wantShadow) {
                     const uint32_t st = (uint32_t)item * RT_BLOCK + threadIdx.x;
                     stageA[st] = make_float4(rayLoc.x, rayLoc.y, rayLoc.z, rayDir.x);
-                    stageB[st] = make_float4(rayDir.y, rayDir.z, __uint_as_float(refracting ? RT_FLAG_REFRACTING : 0u), __uint_as_float(slot));
-                    if (cont) stageS[st] = make_float4(strength.x, strength.y, strength.z, 0.f);
+                    stageB[st] = make_float4(rayDir.y, rayDir.z, strength.x, strength.y);
+                    stageC[st] = strength.z;
+                    if (refracting) refrMask |= 1u << item;
+#pragma unroll
+                    for (int k = 0; k < RT_ITEMS; k++) if (item == k) slotK[k] = slot;
                 }
                 if (wantShadow && F.anyPoint) P.shadeLoc[slot] = make_float4(hitLoc.x, hitLoc.y, hitLoc.z, 0.f);
             }
@@ -797,11 +802,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
           if (flag[0][k] | flag[1][k]) {
               const uint32_t st = (uint32_t)k * RT_BLOCK + threadIdx.x;
               const float4 a = stageA[st], b = stageB[st];
+              const float sl = __uint_as_float(slotK[k]);
               if (flag[0][k]) {
                   const uint32_t o = idx[0][k];
-                  raysOut[2u * o] = a; raysOut[2u * o + 1u] = b; raySOut[o] = stageS[st];
+                  raysOut[2u * o] = a;
+                  raysOut[2u * o + 1u] = make_float4(b.x, b.y, __uint_as_float(((refrMask >> k) & 1u) ? RT_FLAG_REFRACTING : 0u), sl);
+                  raySOut[o] = make_float4(b.z, b.w, stageC[st], 0.f);
               }
-              if (flag[1][k]) P.shadowRec[idx[1][k]] = make_float4(a.x, a.y, a.z, b.w);
+              if (flag[1][k]) P.shadowRec[idx[1][k]] = make_float4(a.x, a.y, a.z, sl);
           }
       }
     }
