@@ -56,7 +56,7 @@ struct rt_ctx {
     bool primValid = false;
 
     // path state
-    // Up to four sets of per-pass path buffers: consecutive passes run on `passStreams` streams, so that the small, tail-dominated
+    // Up to kMaxSets sets of per-pass path buffers: consecutive passes run on `passStreams` streams, so that the small, tail-dominated
     // launches of one pass's late bounces overlap the large launches of the next pass (only k_resolve is ordered).
     struct PathSet { DevBuf ray[2], rayS[2], hit, shadowRec, shadeLoc, contrib, depth, counters, overflow; };
     static constexpr int kMaxSets = 8;
