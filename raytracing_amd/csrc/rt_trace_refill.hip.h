@@ -248,11 +248,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                     const float4 rec = P.shadowRec[q];
                     const uint32_t slot = __float_as_uint(rec.w);
                     float* wp_ = &P.contrib[((size_t)bounce * P.lightSlots + l) * P.nslots + slot].w;
-                    if (*wp_ == 1.f) {
+                    // one light: every queued entry awaits its shadow ray (k_shade queued it for that reason), so the
+                    // scattered read of the flag is not needed
+                    if (L == 1u || *wp_ == 1.f) {
                         o = mk(rec.x, rec.y, rec.z); shadeLoc = mk(0.f, 0.f, 0.f);
                         if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; shadeLoc = mk(h4.x, h4.y, h4.z); }
-                        const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
-                        float4 L0 = lp[0], L1 = lp[1];
+                        float4 L0, L1;
+                        if (L == 1u) {         // kernarg, uniform: scalar loads
+                            const RefLight& Lg = F.lights[0];
+                            L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength);
+                            L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, __uint_as_float(Lg.lightType));
+                        } else {
+                            const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
+                            L0 = lp[0]; L1 = lp[1];
+                        }
                         kind = (int)__float_as_uint(L1.w);
                         distToLight = 0.f;
                         if (kind == 0) {
