@@ -269,7 +269,6 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     rt_status s = sync_scene(c);
     if (s) return s;
     if ((uint64_t)c->numLights > c->nLights) return fail(c, RT_ERR_INVALID, "numLights exceeds the light buffer (slot 5)");
-    if (c->numLights > RT_MAX_LIGHTS) return fail(c, RT_ERR_INVALID, "numLights exceeds RT_MAX_LIGHTS");
     auto t0 = std::chrono::steady_clock::now();
 
     FrameParams F;

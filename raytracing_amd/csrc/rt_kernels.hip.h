@@ -90,6 +90,12 @@ __device__ __forceinline__ void block_append(const bool (&flag)[NQ][RT_ITEMS], u
     (void)waveTotal;
 }
 
+// Light l of slot 5: the first RT_MAX_LIGHTS travel in the kernel argument segment (uniform index: scalar loads),
+// further ones are read from the uploaded buffer.
+__device__ __forceinline__ RefLight light_at(const SceneView& S, const FrameParams& F, int l) {
+    return l < RT_MAX_LIGHTS ? F.lights[l] : S.lights[l];
+}
+
 __device__ __forceinline__ void slot_to_pixel(const FrameParams& F, uint32_t slot, int* px, int* py) {
     uint32_t tile = slot >> 6, l = slot & 63u;
     uint32_t tx = tile % (uint32_t)F.tilesX, ty = tile / (uint32_t)F.tilesX;
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 // light loop, shader.comp:453-522 minus the shadow lineCast (k_shadow)
                 if (F.numLights == 0) logp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int l = 0; l < F.numLights; l++) {
-                    const RefLight& Lg = F.lights[l];      // kernarg, uniform index: scalar loads
+                    const RefLight Lg = light_at(S, F, l);
                     float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, __uint_as_float(Lg.lightType)), L2 = make_float4(Lg.color.x, Lg.color.y, Lg.color.z, 0.f);
                     uint32_t ltype = __float_as_uint(L1.w);
                     v3 dirToLight = mk(0.f, 0.f, 0.f);
@@ -841,7 +847,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
         for (int l = 0; l < F.numLights; l++) {
             float* wp = &logp[(size_t)l * P.nslots].w;
             if (F.numLights > 1 && *wp != 1.f) continue;     // (one light: a queued slot always awaits its shadow ray)
-            const RefLight& Lg = F.lights[l];      // kernarg, uniform index: scalar loads
+            const RefLight Lg = light_at(S, F, l);
             float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, 0.f);
             uint32_t ltype = Lg.lightType;
             v3 dirToLight; float distToLight = 0.f;

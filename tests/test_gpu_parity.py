@@ -210,3 +210,27 @@ def test_several_lights_bit_exact(oracle_lib, models_root, scene_id, knobs):
     assert st["rays_bounce"] == ost["rays_bounce"]
     assert st["rays_shadow"] + st["rays_shadow_skipped"] == ost["rays_shadow"]
     cs.Delete()
+
+
+@pytest.mark.parametrize("knobs", [{}, {"refill": 1}])
+def test_ten_lights_bit_exact(oracle_lib, models_root, knobs):
+    """More lights than the copy in the kernel argument segment holds (8): the rest are read from slot 5."""
+    from oracle import gltf_flatten as G
+    from raytracing_amd import ComputeShader
+    lights = [((2.0 * k - 9.0, 4.0 + 0.25 * k, 3.0 - 0.5 * k), (0.3 * k - 1.0, -1.0, 0.5), k % 2, 8.0 + k) for k in range(10)]
+    flat = G.load_scene(models_root, 4)
+    flat["lights"], flat["hasSun"] = G.lights_to_gpu(lights)
+    sc = oracle_lib.Scene(flat)
+    W, H, spp, b = 64, 40, 2, 4
+    want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, b)
+    for k, v in knobs.items():
+        cs.setInt(k, v)
+    cs.dispatch()
+    for k, name in enumerate(("color", "albedo", "normal", "depth")):
+        bad = ~same_floats(cs.get_image(k), want[name])
+        assert not bad.any(), "%s: %d floats differ" % (name, int(bad.sum()))
+    st, ost = cs.stats(), want["stats"]
+    assert st["rays_shadow"] + st["rays_shadow_skipped"] == ost["rays_shadow"]
+    cs.Delete()
