@@ -68,16 +68,26 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
 }
 
 // Closest hit == lineCast (shader.comp:243-290) for the rays of `queue` (PRIMARY: the camera rays of all slots).
+//
+// Ray set-up (fetch, 1/d, root box) is done for a whole 64-ray group at a time with every lane of the wave working,
+// whatever the lanes' own rays are doing, and the prepared rays wait in a per-wave LDS pool; a refill then costs an
+// idle lane a few LDS reads.  (Setting rays up inside the refill, with only the idle lanes active, made every refill
+// as expensive as a full wave's set-up.)
+#define RT_POOL_WORDS 10     // o.xyz, d.xyz, 1/d.xyz, queue entry
 template <bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
                                                          const float4* __restrict__ rays, const uint32_t* __restrict__ count,
                                                          int rBase, uint32_t rayCount, int refillIdle,
                                                          DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    __shared__ float poolMem[RT_BLOCK / 64][RT_POOL_WORDS][64];
     const Stack stk = make_stack(lds, P);
+    float (*pool)[64] = poolMem[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = *count;
     const float INF = __int_as_float(0x7f800000);
     WavePool wp = wave_pool(n);
+    uint32_t poolN = 0;          // prepared rays waiting in the pool (wave-uniform)
     uint32_t nNodes = 0, nTris = 0, maxSteps = 0, steps0 = 0;
 
     bool active = false;
@@ -101,50 +111,80 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FramePa
     for (;;) {
         const unsigned long long idleMask = __ballot(!active);
         const int nIdle = __popcll(idleMask);
-        if (!wp.empty() && nIdle >= refillIdle) {
-            {
-                const uint32_t pre = lane_prefix(idleMask);
-                const uint32_t avail = wp.end - wp.next;
-                if (!active && pre < avail) {
-                    const uint32_t i = wp.next + pre;
-                    bool ok = true;
+        if (nIdle >= refillIdle && (poolN > 0u || !wp.empty())) {
+            if (poolN == 0u) {
+                // set-up stage: lane l prepares ray wp.next + l of the wave's current group
+                const uint32_t i = wp.next + lane;
+                const bool have = i < wp.end;
+                v3 ro = mk(0.f, 0.f, 0.f), rd = mk(1.f, 1.f, 1.f);
+                bool ok = have;
+                if (have) {
                     if (PRIMARY) {
-                        slot = i;
                         int px, py, r;
-                        o = ld3(F.camPos);
-                        ok = primary_ray(F, P, rBase, slot, &px, &py, &r, &d);
-                        if (!ok) P.hit[slot] = make_float2(0.f, __int_as_float(-2));
+                        ro = ld3(F.camPos);
+                        ok = primary_ray(F, P, rBase, i, &px, &py, &r, &rd);
+                        if (!ok) P.hit[i] = make_float2(0.f, __int_as_float(-2));
                     } else {
-                        slot = i;                 // entry index: where the hit record goes
                         uint32_t fl, pathSlot;
-                        unpack_ray(rays[2u * i], rays[2u * i + 1u], o, d, fl, pathSlot);
-                    }
-                    if (ok) {
-                        if (!ray_is_plain(o, d)) {
-                            HitRec best;
-                            closest_hit<false, COUNT, false>(S, o, d, stk, best, nNodes, nTris);
-                            P.hit[slot] = make_float2(best.t, __int_as_float(best.ref));
-                        } else {
-                            v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                            float te;
-                            if (COUNT) { nNodes++; steps0 = nNodes + nTris; }
-                            if (!slab<true>(o, inv, S.rootLo, S.rootHi, &te)) {
-                                P.hit[slot] = make_float2(__int_as_float(0x7f800000), __int_as_float(-1));
-                            } else {
-                                R = make_pairs(o, inv);
-                                bestT = INF; bestDist = 3.40282347e+38f; lim = INF; bestIdx = -1; bestRef = -1;
-                                sp = 0; cur = S.rootChild;
-                                active = true;
-                            }
-                        }
+                        unpack_ray(rays[2u * i], rays[2u * i + 1u], ro, rd, fl, pathSlot);
                     }
                 }
-                wp.take(((uint32_t)nIdle < avail) ? (uint32_t)nIdle : avail);
+                // Rays that could produce a NaN in a slab test (zero / non-finite direction component) go through the pool
+                // too, marked in the top bit of their entry: the idle lane that receives one traces it on the spot with the
+                // select-form routine (its own stack is empty then).
+                bool ready = false, plain = true;
+                v3 inv = mk(1.f, 1.f, 1.f);
+                if (ok) {
+                    plain = ray_is_plain(ro, rd);
+                    ready = true;
+                    if (plain) {
+                        inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        float te;
+                        if (COUNT) nNodes++;
+                        if (!slab<true>(ro, inv, S.rootLo, S.rootHi, &te)) { P.hit[i] = make_float2(INF, __int_as_float(-1)); ready = false; }
+                    }
+                }
+                const unsigned long long rm = __ballot(ready);
+                if (ready) {
+                    const uint32_t e = lane_prefix(rm);
+                    pool[0][e] = ro.x; pool[1][e] = ro.y; pool[2][e] = ro.z;
+                    pool[3][e] = rd.x; pool[4][e] = rd.y; pool[5][e] = rd.z;
+                    pool[6][e] = inv.x; pool[7][e] = inv.y; pool[8][e] = inv.z;
+                    pool[9][e] = __uint_as_float(plain ? i : (i | 0x80000000u));
+                }
+                poolN = (uint32_t)__popcll(rm);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                wp.take(wp.end - wp.next);
                 continue;
             }
-        }
-        if (nIdle == 64) break;
-        const bool canRefill = !wp.empty();
+            // hand prepared rays to the idle lanes (from the top of the pool)
+            const uint32_t pre = lane_prefix(idleMask);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!active && pre < poolN) {
+                const uint32_t e = poolN - 1u - pre;
+                o = mk(pool[0][e], pool[1][e], pool[2][e]);
+                d = mk(pool[3][e], pool[4][e], pool[5][e]);
+                const v3 inv = mk(pool[6][e], pool[7][e], pool[8][e]);
+                slot = __float_as_uint(pool[9][e]);
+                if (slot & 0x80000000u) {
+                    slot &= 0x7fffffffu;
+                    HitRec best;
+                    closest_hit<false, COUNT, false>(S, o, d, stk, best, nNodes, nTris);
+                    P.hit[slot] = make_float2(best.t, __int_as_float(best.ref));
+                } else {
+                    R = make_pairs(o, inv);
+                    bestT = INF; bestDist = 3.40282347e+38f; lim = INF; bestIdx = -1; bestRef = -1;
+                    sp = 0; cur = S.rootChild;
+                    if (COUNT) steps0 = nNodes + nTris;
+                    active = true;
+                }
+            }
+            poolN -= ((uint32_t)nIdle < poolN) ? (uint32_t)nIdle : poolN;
+            __builtin_amdgcn_wave_barrier();
+            if (poolN == 0u && !wp.empty()) continue;      // still idle lanes to feed: prepare the next group first
+        } else if (nIdle == 64) break;
+        const bool canRefill = poolN > 0u || !wp.empty();
 
         for (;;) {
             while (cur >= 0) {
