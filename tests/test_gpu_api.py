@@ -249,3 +249,30 @@ def test_full_size_frame_is_reproducible_and_stream_independent(oracle_lib, scen
         for k in knobs:
             cs.setInt(k, {"passStreams": 0, "samplesPerPass": 64, "autoPass": 1, "refill": -1, "blocksPerCU": 64}[k])
     cs.Delete()
+
+
+def test_contexts_release_their_device_memory(scene4):
+    """rt_destroy (ComputeShader::Delete) frees images, scene, path buffers, streams and events: free device memory after
+    twelve create / render / destroy rounds is what it was after the first."""
+    import ctypes
+    from raytracing_amd import ComputeShader
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    def one_round():
+        cs = ComputeShader()
+        setup_core(cs, scene4, 256, 144, 8, 4)
+        cs.dispatch()
+        cs.setInt("timeKernels", 1)
+        cs.dispatch_region(0, 0, 256, 144, 0, 8)
+        cs.Delete()
+
+    one_round()
+    before = free_bytes()
+    for _ in range(12):
+        one_round()
+    assert free_bytes() >= before - (64 << 20)      # allocator granularity, not a per-round loss
