@@ -43,6 +43,30 @@ def test_load_models_explicit_list(models_root):
     assert len(lights) == 1 and lights["lightType"][0] == 0 and np.isnan(lights["dir"][0]).all()   # normalize(0) = NaN
 
 
+# Scene 1 of the reference's table (Scene.cpp:28-31) without its first model, whose base colour is a progressive JPEG
+# (no decoder here): five models, two point lights; the cube is normal-mapped, the glass sphere transmissive.
+SCENE1_MODELS = ["cube/cube.gltf", "sphere1/sphere.gltf", "glassSphere/sphere.gltf", "walls/walls.gltf", "roughSphere/roughSphere.gltf"]
+SCENE1_LIGHTS = [((2, 5, 0), (0, 0, 0), 0, 50.0), ((-2, 5, 0), (0, 0, 0), 0, 50.0)]
+
+
+def test_five_model_scene_buffers_match_oracle(oracle_lib, models_root):
+    """Several models in one scene: vertex / mesh / material offsets of Model::BVH (model.cpp:562-582), texture handles in
+    load order, normal-map material (cube) next to untextured glass."""
+    from raytracing_amd import scene as S
+    paths = [models_root + "/" + m for m in SCENE1_MODELS]
+    S.Scene.LoadModels(None, paths, SCENE1_LIGHTS)
+    flat = G.flatten(paths)
+    flat["lights"], flat["hasSun"] = G.lights_to_gpu(SCENE1_LIGHTS)
+    for slot, (key, dt) in SLOTS.items():
+        got = np.frombuffer(S.Scene.buffer(slot), dt)
+        assert len(got) == len(flat[key]), key
+        assert _same(got, flat[key]), key
+    assert np.array_equal(np.frombuffer(S.Scene.buffer(1), np.float32).reshape(-1, 4, 4), flat["matrices"])
+    assert _same(np.frombuffer(S.Scene.buffer(3), G.NODE_DT), oracle_lib.build_bvh(flat["triangles"]))
+    m = flat["materials"]
+    assert m["hasNormalTexture"][0] == 1 and m["hasBaseTexture"][0] == 1 and m["transmissionFactor"][2] == 1
+
+
 def test_material_quirks(models_root):
     """ior defaults to -1 without KHR_materials_ior, metallicFactor to 1 when absent (model.cpp:266-276)."""
     from raytracing_amd import scene as S
@@ -58,7 +82,7 @@ def test_material_quirks(models_root):
 
 def test_png_decoder_matches_pil(oracle_lib, models_root):
     from raytracing_amd import scene as S
-    for rel in ("box/Untitled.png", "walls/Untitled.png"):
+    for rel in ("box/Untitled.png", "walls/Untitled.png", "cube/normal_mapping_normal_map.png", "sphere1/baseColor.png"):
         assert np.array_equal(S.decode_png(models_root + "/" + rel), oracle_lib.decode_texture(models_root + "/" + rel))
 
 
