@@ -268,3 +268,30 @@ def test_five_model_scene_bit_exact(oracle_lib, models_root, knobs):
     hit_mats = set(np.unique(sc.triangles["materialIndex"][tri[tri >= 0]]).tolist())
     assert {0, 2} <= hit_mats, "the view must show the normal-mapped cube and the glass sphere (materials %r)" % (hit_mats,)
     cs.Delete()
+
+
+def test_all_texture_slots_bit_exact(oracle_lib, scenes):
+    """Every material of scene 3 made to sample base colour, normal map and metallic-roughness (shader.comp:363-383,
+    434-436) from the scene's one texture: no bundled model that decodes here has a metallic-roughness map, so the flags
+    are set by hand on the uploaded MaterialData records; oracle and core read the same records."""
+    import copy
+    from raytracing_amd import ComputeShader
+    sc = copy.copy(scenes(3))
+    sc.materials = sc.materials.copy()
+    assert len(sc.textures) >= 1
+    for m in sc.materials:
+        for fld, has in (("baseColorTexture", "hasBaseTexture"), ("normalTexture", "hasNormalTexture"),
+                         ("metallicRoughnessTexture", "hasMetallicRoughnessTexture")):
+            m[fld] = 1
+            m[has] = 1
+    W, H, spp, b = 96, 72, 3, 5
+    want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, b)
+    cs.dispatch()
+    for k, name in enumerate(("color", "albedo", "normal", "depth")):
+        got = cs.get_image(k)
+        bad = ~same_floats(got, want[name])
+        assert not bad.any(), "%s: %d floats differ" % (name, int(bad.sum()))
+    assert not np.array_equal(bits(want["normal"]), bits(oracle_lib.render(scenes(3), oracle_lib.make_params(scenes(3), W, H, spp, b, math_mode=1))["normal"]))
+    cs.Delete()
