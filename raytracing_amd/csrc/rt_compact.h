@@ -111,7 +111,8 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
             grow(wb, a); grow(wb, b); grow(wb, cc);
             cnt++;
         }
-        return -(int32_t)(first * 8u + cnt) - 1;
+        // (a leaf without triangles: any non-zero `first`, so that its code differs from -1 = no child at all)
+        return -(int32_t)((cnt ? first : 1u) * 8u + cnt) - 1;
     };
     auto padBox = [&](const Bounds& wb, float* lo, float* hi) {
         for (int k = 0; k < 3; k++) {

@@ -191,7 +191,10 @@ SceneView make_view(rt_ctx* c, bool exact) {
     return S;
 }
 
-bool use_exact(rt_ctx* c) { return c->traversalMode == 1 || !c->cs.boxesContainTris; }
+// The culled traversal is the reference's result only while the reference's own 64-entry stack cannot fill up (a push
+// it drops changes what it renders, Q10) and while boxes contain what they lead to (Q3): otherwise the reference-order
+// walk, which emulates that stack, is used whatever traversalMode says.
+bool use_exact(rt_ctx* c) { return c->traversalMode == 1 || !c->cs.boxesContainTris || c->cs.maxDepth >= 63; }
 
 // Launch geometry of the persistent traversal / shading kernels and the stack overflow area that goes with it.
 uint32_t trace_blocks(rt_ctx* c, uint32_t nslots) {

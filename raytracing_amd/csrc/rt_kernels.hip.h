@@ -251,6 +251,11 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, cons
     if (!slab<FAST>(o, inv, S.rootLo, S.rootHi, &te)) return false;
     int sp = 0;
     int cur = S.rootChild;
+    // EXACT: number of entries on the reference's own stack (shader.comp:246) while the current node is processed.  The
+    // shader pushes both children of a node while there is room for them (64 entries) and box-tests a node when it pops
+    // it; this walk pushes only siblings whose box passed, so it counts the others: a push the shader would drop for
+    // lack of room is dropped here too, and trees deeper than 64 levels come out as the shader renders them.
+    int refSp = 0;
     const RayPairs R = make_pairs(o, inv);
     auto popNext = [&]() {
         cur = RT_DONE;
@@ -259,7 +264,7 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, cons
             if (!EXACT) {
                 float lim = best.t + best.t * 1e-4f + S.cullAbs;
                 if (__uint_as_float(e.y) > lim) continue;
-            }
+            } else refSp = (int)e.y;          // the sibling's position on the reference stack = entries left below it
             cur = (int)e.x;
             break;
         }
@@ -288,9 +293,13 @@ __device__ __forceinline__ bool closest_hit(const SceneView& S, v3 o, v3 d, cons
                 // the reference pops children.y first (shader.comp:281-284)
                 p0 = p0 || (c0 < 0);
                 p1 = p1 || (c1 < 0);
-                if (p0 && p1) { uint2 e; e.x = (uint32_t)c0; e.y = 0u; stk.push(sp, e); cur = c1; }
-                else if (p1) cur = c1;
-                else if (p0) cur = c0;
+                // children.x, then children.y, each pushed if present and stackPtr < 64 (shader.comp:281-284); y is popped next
+                const int pos0 = refSp;
+                const bool in0 = c0 != -1 && refSp < 64;
+                if (in0) refSp++;
+                const bool in1 = c1 != -1 && refSp < 64;
+                if (in0 && p0) { uint2 e; e.x = (uint32_t)c0; e.y = (uint32_t)pos0; stk.push(sp, e); }
+                if (in1 && p1) cur = c1;
                 else popNext();
             } else {
                 float lim = best.t + best.t * 1e-4f + S.cullAbs;

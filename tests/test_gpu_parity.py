@@ -331,3 +331,72 @@ def test_non_identity_mesh_matrices_bit_exact(oracle_lib, scenes, kind):
         bad = ~same_floats(cs.get_image(k), want[name])
         assert not bad.any(), "%s: %d floats differ" % (name, int(bad.sum()))
     cs.Delete()
+
+
+def _chain_scene(oracle_lib, n_tris):
+    """n_tris small camera-facing triangles on a 10-wide grid under a degenerate BVH: internal node k = (leaf k, internal
+    k + 1), the chain hanging off children.y — the child the shader pops first, so one pending sibling per level piles up
+    on its 64-entry stack (shader.comp:246,281-284)."""
+    from oracle import gltf_flatten as G
+    f32 = np.float32
+    verts = np.zeros(3 * n_tris, G.VERTEX_DT)
+    tris = np.zeros(n_tris, G.TRIANGLE_DT)
+    for i in range(n_tris):
+        cx, cy = f32((i % 10) - 4.5), f32((i // 10) * 0.7 + 0.5)
+        p = np.array([[cx - 0.3, cy - 0.25, 0.0], [cx + 0.3, cy - 0.25, 0.0], [cx, cy + 0.3, 0.0]], f32)
+        verts["position"][3 * i:3 * i + 3] = p
+        verts["normal"][3 * i:3 * i + 3] = (0, 0, 1)
+        verts["color"][3 * i:3 * i + 3] = 1
+        t = tris[i]
+        t["indices"] = (3 * i, 3 * i + 1, 3 * i + 2)
+        t["p1"], t["p2"], t["p3"] = p[0], p[1], p[2]
+        t["centroidLoc"] = (p[0] + p[1] + p[2]) / f32(3)
+        t["minBounds"], t["maxBounds"] = p.min(0), p.max(0)
+    nodes = np.zeros(2 * n_tris - 1, G.NODE_DT)
+    big = np.finfo(f32).max
+
+    def leaf(idx, tri):
+        nodes[idx]["minLoc"], nodes[idx]["maxLoc"], nodes[idx]["isLeaf"] = big, -big, 1        # model.h:138-139
+        nodes[idx]["children"] = (tri, -1, -1, -1)
+    for k in range(n_tris - 1):
+        nodes[2 * k]["minLoc"], nodes[2 * k]["maxLoc"] = (-6, -1, -1), (6, 9, 1)
+        nodes[2 * k]["children"] = (2 * k + 1, 2 * k + 2, -1, -1)
+        leaf(2 * k + 1, k)
+    leaf(2 * n_tris - 2, n_tris - 1)
+    mats = np.zeros(1, G.MATERIAL_DT)
+    mats["baseColorFactor"], mats["metallicFactor"], mats["roughnessFactor"], mats["ior"] = (0.8, 0.6, 0.4, 1.0), 0.0, 0.5, -1.0
+    lights, has_sun = G.lights_to_gpu([((0, 0, 0), (0.2, -0.3, -1.0), 1, 1.0)])
+    flat = {"vertices": verts, "matrices": np.eye(4, dtype=f32)[None], "materials": mats, "triangles": tris,
+            "lights": lights, "hasSun": has_sun}
+    return oracle_lib.Scene(flat, nodes=nodes, textures=[])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_tree_deeper_than_the_reference_stack(oracle_lib, mode):
+    """Q10: a BVH 89 levels deep.  The shader's 64-entry stack silently drops pushes that do not fit, so the deepest
+    triangles are never tested and do not appear; the core renders the same image (a tree that deep switches the default
+    culled traversal to the stack-emulating reference-order walk by itself)."""
+    from raytracing_amd import ComputeShader
+    n = 90
+    sc = _chain_scene(oracle_lib, n)
+    W, H, spp, b = 160, 96, 2, 3
+    want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
+    seen = set(np.unique(want["prim_tri"]).tolist()) - {-1}
+    assert len(seen) >= 55 and (n - 1) not in seen and max(seen) < n - 20, "the reference drops the deep end of the chain"
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, b)
+    cs.setInt("traversalMode", mode)
+    cs.dispatch()
+    tri, _ = cs.primary_hits()
+    assert np.array_equal(tri, want["prim_tri"])
+    for k, name in enumerate(("color", "albedo", "normal", "depth")):
+        bad = ~same_floats(cs.get_image(k), want[name])
+        assert not bad.any(), "%s: %d floats differ" % (name, int(bad.sum()))
+    # a chain short enough for the stack shows every triangle, in both modes
+    sc2 = _chain_scene(oracle_lib, 40)
+    want2 = oracle_lib.render(sc2, oracle_lib.make_params(sc2, W, H, spp, b, math_mode=1))
+    assert set(np.unique(want2["prim_tri"]).tolist()) - {-1} == set(range(40))
+    setup_core(cs, sc2, W, H, spp, b)
+    cs.dispatch()
+    assert same_floats(cs.get_image(0), want2["color"]).all()
+    cs.Delete()
