@@ -71,7 +71,8 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * camUp, aspect, fov, samplesPerPixel, maxBounces, offset.  Unknown names (projection, invProj, view,
  * invView, time ...) are accepted and ignored, as glGetUniformLocation == -1 is in GL.
  * Extension names (no reference counterpart): traversalMode (0 = culled/ordered, 1 = reference-order
- * exhaustive), timeKernels (1 = HIP-event timing per kernel class into rt_stats), countVisits (1 = run the
+ * exhaustive with the shader's 64-entry stack; 0 becomes 1 by itself for a scene on which culling would not give the
+ * reference's result: boxes that do not contain their triangles, trees 63 or more levels deep), timeKernels (1 = HIP-event timing per kernel class into rt_stats), countVisits (1 = run the
  * instrumented traversal kernels that count node visits / triangle tests), samplesPerPass (samples of a pixel
  * traced concurrently; results do not depend on it), blocksPerCU (persistent grid size), passStreams (1..8, default 4: consecutive
  * passes of samplesPerPass samples run on that many HIP streams with their own path buffers and overlap; the per-pixel
