@@ -109,7 +109,6 @@ std::vector<Model*> Model::instances;
 double Model::lastFlattenSeconds = 0, Model::lastBuildSeconds = 0, Model::lastUploadSeconds = 0;
 
 Model::Model(const char* f) : file(f) {
-    instances.push_back(this);
     std::vector<uint8_t> text = read_file_bytes(file);
     JSON = Json::parse(std::string(text.begin(), text.end()));
     // getData, model.cpp:149-162
@@ -117,6 +116,8 @@ Model::Model(const char* f) : file(f) {
     std::string dir = file.substr(0, file.find_last_of('/') + 1);
     data = read_file_bytes(dir + uri);
     traverseNode(0);
+    // registered last: a constructor that throws (missing file, bad JSON) must not leave a dangling entry for DeleteAll
+    instances.push_back(this);
 }
 
 // model.cpp:164-196

@@ -91,6 +91,10 @@ def test_missing_file_is_an_error(models_root):
     from raytracing_amd.core import RtError
     with pytest.raises(RtError):
         S.Scene.LoadScene(None, 6, models_root)   # Dragon.bin is absent from the reference checkout
+    # the failed load leaves nothing behind: the next scene loads (a Model that threw in its constructor used to stay
+    # registered and was freed twice here)
+    S.Scene.LoadScene(None, 4, models_root)
+    assert len(np.frombuffer(S.Scene.buffer(4), G.TRIANGLE_DT)) == 4802
 
 
 def test_camera_helpers_match_oracle():
