@@ -1,0 +1,98 @@
+// Host-side sanitizer run of the loader / BVH builder / PNG decoder (no GPU needed: ctx == NULL is the loader's dry run).
+// Build and run: tools/sanitize/run.sh   (g++ -fsanitize=address,undefined on csrc/host/rt_host.cpp; the rt_* core entry
+// points the host layer links against are answered by "no device" stand-ins below; a dry run never calls them).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_core.h"
+#include "../../include/rt_host.h"
+
+// The GPU core is not part of this run (a dry run never reaches it): its entry points, which the host layer links
+// against, answer "no device" here.  (Linking librt_core.so instead would define the host layer's statics twice.)
+extern "C" {
+rt_status rt_create(rt_ctx** out, const rt_config*) { if (out) *out = nullptr; return RT_ERR_NO_DEVICE; }
+void rt_destroy(rt_ctx*) {}
+const char* rt_last_error(const rt_ctx*) { return "no device in the sanitizer run"; }
+rt_status rt_upload_buffer(rt_ctx*, uint32_t, const void*, uint64_t) { return RT_ERR_NO_DEVICE; }
+rt_status rt_set_int(rt_ctx*, const char*, int32_t) { return RT_ERR_NO_DEVICE; }
+rt_status rt_set_float(rt_ctx*, const char*, float) { return RT_ERR_NO_DEVICE; }
+rt_status rt_set_vec2(rt_ctx*, const char*, const float[2]) { return RT_ERR_NO_DEVICE; }
+rt_status rt_set_vec3(rt_ctx*, const char*, const float[3]) { return RT_ERR_NO_DEVICE; }
+rt_status rt_set_vec4(rt_ctx*, const char*, const float[4]) { return RT_ERR_NO_DEVICE; }
+rt_status rt_set_mat4(rt_ctx*, const char*, const float[16]) { return RT_ERR_NO_DEVICE; }
+rt_status rt_create_texture(rt_ctx*, const uint8_t*, uint32_t, uint32_t, uint64_t*) { return RT_ERR_NO_DEVICE; }
+rt_status rt_read_image(rt_ctx*, uint32_t, float*) { return RT_ERR_NO_DEVICE; }
+}
+
+static int fails = 0;
+#define EXPECT(c) do { if (!(c)) { std::fprintf(stderr, "FAILED %s:%d: %s (%s)\n", __FILE__, __LINE__, #c, rth_last_error()); fails++; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <models_root>\n", argv[0]); return 2; }
+    const std::string root = argv[1];
+    const void* p; uint64_t n;
+    for (int round = 0; round < 2; round++) {
+        for (int scene : {2, 3, 4, 7}) {
+            EXPECT(rth_load_scene(nullptr, root.c_str(), scene) == RT_OK);
+            for (uint32_t slot = 0; slot < 6; slot++) EXPECT(rth_scene_buffer(slot, &p, &n) == RT_OK && n > 0);
+        }
+        EXPECT(rth_load_scene(nullptr, root.c_str(), 6) != RT_OK);          // files missing: error, then a clean reload
+        EXPECT(rth_load_scene(nullptr, root.c_str(), 99) != RT_OK);
+        EXPECT(rth_load_scene(nullptr, (root + "/nowhere").c_str(), 4) != RT_OK);
+        EXPECT(rth_load_scene(nullptr, root.c_str(), 4) == RT_OK);
+    }
+    {   // explicit model list with two lights
+        std::vector<std::string> m = {root + "/cube/cube.gltf", root + "/sphere1/sphere.gltf", root + "/glassSphere/sphere.gltf",
+                                      root + "/walls/walls.gltf", root + "/roughSphere/roughSphere.gltf"};
+        std::vector<const char*> mp; for (auto& s : m) mp.push_back(s.c_str());
+        const float lights[2][8] = {{2, 5, 0, 0, 0, 0, 0, 50}, {-2, 5, 0, 0, 0, 0, 0, 50}};
+        EXPECT(rth_load_models(nullptr, mp.data(), (int32_t)mp.size(), &lights[0][0], 2) == RT_OK);
+        EXPECT(rth_scene_buffer(4, &p, &n) == RT_OK && n % 128 == 0);
+        // the builder alone on that triangle buffer, and on degenerate input (five identical triangles: an error, not a crash)
+        void* nodes = nullptr; uint64_t nn = 0;
+        EXPECT(rth_build_bvh(p, n / 128, &nodes, &nn) == RT_OK && nn > 0);
+        rth_free(nodes);
+        std::vector<uint8_t> same(5 * 128);
+        for (int k = 0; k < 5; k++) std::memcpy(same.data() + 128 * k, p, 128);
+        nodes = nullptr;
+        EXPECT(rth_build_bvh(same.data(), 5, &nodes, &nn) != RT_OK);
+        rth_free(nodes);
+        EXPECT(rth_build_bvh(p, 0, &nodes, &nn) != RT_OK || nn == 0 || (rth_free(nodes), true));
+    }
+    {   // PNG decoder: good files, a missing file, a truncated copy, garbage
+        uint8_t* px = nullptr; uint32_t w = 0, h = 0;
+        EXPECT(rth_decode_png((root + "/box/Untitled.png").c_str(), &px, &w, &h) == RT_OK && w > 0 && h > 0);
+        rth_free(px); px = nullptr;
+        EXPECT(rth_decode_png((root + "/cube/normal_mapping_normal_map.png").c_str(), &px, &w, &h) == RT_OK);
+        rth_free(px); px = nullptr;
+        EXPECT(rth_decode_png((root + "/none.png").c_str(), &px, &w, &h) != RT_OK);
+        std::string src = root + "/box/Untitled.png";
+        FILE* f = std::fopen(src.c_str(), "rb");
+        std::vector<uint8_t> bytes;
+        if (f) { uint8_t buf[4096]; size_t k; while ((k = std::fread(buf, 1, sizeof buf, f)) > 0) bytes.insert(bytes.end(), buf, buf + k); std::fclose(f); }
+        const char* tmp = "/tmp/rt_asan_trunc.png";
+        for (size_t cut : {bytes.size() / 2, (size_t)40, (size_t)8, (size_t)0}) {
+            f = std::fopen(tmp, "wb"); std::fwrite(bytes.data(), 1, cut, f); std::fclose(f);
+            px = nullptr;
+            EXPECT(rth_decode_png(tmp, &px, &w, &h) != RT_OK);
+            rth_free(px);
+        }
+        std::vector<uint8_t> bad = bytes;
+        for (size_t k = 100; k < bad.size(); k += 97) bad[k] ^= 0x5a;                 // corrupt the deflate stream / CRCs
+        f = std::fopen(tmp, "wb"); std::fwrite(bad.data(), 1, bad.size(), f); std::fclose(f);
+        px = nullptr;
+        (void)rth_decode_png(tmp, &px, &w, &h);                                       // either outcome, but no memory error
+        rth_free(px);
+        std::remove(tmp);
+    }
+    {   // camera helpers
+        float pos[3], ori[3];
+        for (int fr : {0, 1, 60, 119}) rth_orbit_camera(fr, pos, ori);
+    }
+    (void)rth_load_scene(nullptr, root.c_str(), 99);       // unloads, then fails: what is left at exit now is a leak
+    std::printf("host sanitizer run: %d failed expectation(s)\n", fails);
+    return fails ? 1 : 0;
+}
