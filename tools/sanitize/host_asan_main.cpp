@@ -9,6 +9,7 @@
 
 #include "../../include/rt_core.h"
 #include "../../include/rt_host.h"
+#include "../../raytracing_amd/csrc/rt_compact.h"     // what rt_render_* runs on the uploaded buffers before the first launch
 
 // The GPU core is not part of this run (a dry run never reaches it): its entry points, which the host layer links
 // against, answer "no device" here.  (Linking librt_core.so instead would define the host layer's statics twice.)
@@ -87,6 +88,29 @@ int main(int argc, char** argv) {
         (void)rth_decode_png(tmp, &px, &w, &h);                                       // either outcome, but no memory error
         rth_free(px);
         std::remove(tmp);
+    }
+    {   // the core's compaction of uploaded buffers: a good scene, then inconsistent ones (errors, never memory errors)
+        EXPECT(rth_load_scene(nullptr, root.c_str(), 7) == RT_OK);
+        const void* b[6]; uint64_t nb[6];
+        for (uint32_t slot = 0; slot < 6; slot++) EXPECT(rth_scene_buffer(slot, &b[slot], &nb[slot]) == RT_OK);
+        auto run = [&](const std::vector<uint8_t>& nodes, const std::vector<uint8_t>& tris) {
+            rt::CompactScene cs;
+            return rt::compact_scene((const rt::RefVertex*)b[0], nb[0] / 80, (const rt::RefMat4*)b[1], nb[1] / 64, nb[2] / 80,
+                                     (const rt::RefNode*)nodes.data(), nodes.size() / 48, (const rt::RefTriangle*)tris.data(), tris.size() / 128, cs);
+        };
+        const std::vector<uint8_t> nodes((const uint8_t*)b[3], (const uint8_t*)b[3] + nb[3]), tris((const uint8_t*)b[4], (const uint8_t*)b[4] + nb[4]);
+        EXPECT(run(nodes, tris).empty());
+        auto node = [](std::vector<uint8_t>& v, size_t i) { return (rt::RefNode*)(v.data() + 48 * i); };
+        { auto n2 = nodes; node(n2, 0)->children[1] = 0; EXPECT(!run(n2, tris).empty()); }                       // cycle
+        { auto n2 = nodes; node(n2, 0)->children[0] = (int32_t)(nodes.size() / 48); EXPECT(!run(n2, tris).empty()); }   // child out of range
+        { auto n2 = nodes; node(n2, 0)->children[0] = -7; EXPECT(!run(n2, tris).empty()); }
+        { auto n2 = nodes; node(n2, 0)->children[0] = -1; EXPECT(run(n2, tris).empty()); }                       // absent child: legal
+        { auto n2 = nodes; for (size_t i = 0; i < n2.size() / 48; i++) if (node(n2, i)->isLeaf == 1) { node(n2, i)->children[0] = 1 << 30; break; } EXPECT(!run(n2, tris).empty()); }
+        { auto t2 = tris; ((rt::RefTriangle*)t2.data())->indices[2] = 0xffffffffu; EXPECT(!run(nodes, t2).empty()); }
+        { auto t2 = tris; ((rt::RefTriangle*)t2.data())->meshIndex = 1000; EXPECT(!run(nodes, t2).empty()); }
+        { auto t2 = tris; ((rt::RefTriangle*)t2.data())->materialIndex = 1000; EXPECT(!run(nodes, t2).empty()); }
+        { std::vector<uint8_t> none; EXPECT(!run(none, tris).empty()); }
+        { auto n2 = nodes; n2.resize(48); node(n2, 0)->isLeaf = 1; for (int k = 0; k < 4; k++) node(n2, 0)->children[k] = k; EXPECT(run(n2, tris).empty()); }   // a lone leaf root
     }
     {   // camera helpers
         float pos[3], ori[3];
