@@ -426,8 +426,10 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             evEnd(e);
             e = evBegin(1);
             {
-                auto shadeK = c->anyTextured ? k_shade<true, true>
-                                             : (c->anyTransmissive ? k_shade<false, true> : k_shade<false, false>);
+                const bool many = F.numLights > RT_MAX_LIGHTS;
+                auto shadeK = c->anyTextured ? (many ? k_shade<true, true, true> : k_shade<true, true, false>)
+                            : c->anyTransmissive ? (many ? k_shade<false, true, true> : k_shade<false, true, false>)
+                                                 : (many ? k_shade<false, false, true> : k_shade<false, false, false>);
                 shadeK<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(qcount + b), qcount + b + 1,
                                                  scount + b, (int)rBase, (int)b, iAlb, iNor, iDep, pTri, pHit, dst);
             }

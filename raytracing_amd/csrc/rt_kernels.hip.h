@@ -92,8 +92,20 @@ __device__ __forceinline__ void block_append(const bool (&flag)[NQ][RT_ITEMS], u
 
 // Light l of slot 5: the first RT_MAX_LIGHTS travel in the kernel argument segment (uniform index: scalar loads),
 // further ones are read from the uploaded buffer.
+// (The buffer read is volatile so that it stays behind its branch: written as a select, the compiler fetched the
+// global record per lane for every light of every path, which cost k_shade 12 %.)
 __device__ __forceinline__ RefLight light_at(const SceneView& S, const FrameParams& F, int l) {
-    return l < RT_MAX_LIGHTS ? F.lights[l] : S.lights[l];
+    RefLight Lg = F.lights[l & (RT_MAX_LIGHTS - 1)];
+    if (l >= RT_MAX_LIGHTS) {
+        const volatile uint32_t* p = reinterpret_cast<const volatile uint32_t*>(S.lights + l);
+        uint32_t w[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) w[k] = p[k];
+        Lg.loc.x = __uint_as_float(w[0]); Lg.loc.y = __uint_as_float(w[1]); Lg.loc.z = __uint_as_float(w[2]); Lg.strength = __uint_as_float(w[3]);
+        Lg.dir.x = __uint_as_float(w[4]); Lg.dir.y = __uint_as_float(w[5]); Lg.dir.z = __uint_as_float(w[6]); Lg.lightType = w[7];
+        Lg.color.x = __uint_as_float(w[8]); Lg.color.y = __uint_as_float(w[9]); Lg.color.z = __uint_as_float(w[10]); Lg.pad1 = __uint_as_float(w[11]);
+    }
+    return Lg;
 }
 
 __device__ __forceinline__ void slot_to_pixel(const FrameParams& F, uint32_t slot, int* px, int* py) {
@@ -529,8 +541,9 @@ __device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float a
 // shader.comp:329-452 and 524-531 for one path; light loop body 486-521 is evaluated here and its
 // result parked in `pend` until k_shadow has traced the shadow ray (453-484).
 // TEX / GLASS: the scene has a textured (or normal-mapped) material / a transmissive one.  Scenes without them run a
-// variant with those branches compiled out: fewer live registers on the common path.
-template <bool TEX, bool GLASS>
+// variant with those branches compiled out: fewer live registers on the common path.  MANY: more lights than travel in
+// the kernel arguments (RT_MAX_LIGHTS); otherwise every light is a scalar kernarg read.
+template <bool TEX, bool GLASS, bool MANY>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, PathBuffers P,
                                                     const uint32_t* __restrict__ count, uint32_t* countOut,
                                                     uint32_t* shadowCountOut, int rBase, int bounce,
@@ -733,7 +746,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 // light loop, shader.comp:453-522 minus the shadow lineCast (k_shadow)
                 if (F.numLights == 0) logp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int l = 0; l < F.numLights; l++) {
-                    const RefLight Lg = light_at(S, F, l);
+                    const RefLight Lg = MANY ? light_at(S, F, l) : F.lights[l];
                     float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, __uint_as_float(Lg.lightType)), L2 = make_float4(Lg.color.x, Lg.color.y, Lg.color.z, 0.f);
                     uint32_t ltype = __float_as_uint(L1.w);
                     v3 dirToLight = mk(0.f, 0.f, 0.f);
