@@ -179,6 +179,9 @@ struct HitRec { float dist; float t; int idx; int ref; v3 loc; };
 // shader.comp:104-125 + 269-276 on a pre-transformed triangle (A, B, C = the record's three 16-byte words).
 template <bool EXACT>
 __device__ __forceinline__ void test_tri(float4 A, float4 B, float4 C, int idx, v3 o, v3 d, HitRec& best) {
+    // All three words of the record are fetched before the determinant test: it almost never rejects, and left to
+    // itself the compiler sinks the load of v0 behind it, a second dependent round trip per triangle.
+    asm volatile("" : "+v"(A.x), "+v"(A.y), "+v"(A.z));
     v3 v0 = mk(A.x, A.y, A.z), e1 = mk(A.w, B.x, B.y), e2 = mk(B.z, B.w, C.x);
     v3 pv = cross3(d, e2);
     float det = dot3(e1, pv);

@@ -18,6 +18,7 @@ namespace rt {
 
 // shader.comp:104-125 on a pre-transformed triangle: true + t on a hit.
 __device__ __forceinline__ bool tri_t(float4 A, float4 B, float4 C, v3 o, v3 d, float* tOut) {
+    asm volatile("" : "+v"(A.x), "+v"(A.y), "+v"(A.z));     // see test_tri: keep the load of v0 in front of the determinant test
     v3 v0 = mk(A.x, A.y, A.z), e1 = mk(A.w, B.x, B.y), e2 = mk(B.z, B.w, C.x);
     v3 pv = cross3(d, e2);
     float det = dot3(e1, pv);
