@@ -110,6 +110,12 @@ rt_status rt_render_region(rt_ctx* ctx, uint32_t x, uint32_t y, uint32_t w, uint
 rt_status rt_read_image(rt_ctx* ctx, uint32_t image, float* dst_rgba);
 /* Replaces glTexSubImage2D write-back after denoise (main.cpp:184). */
 rt_status rt_write_image(rt_ctx* ctx, uint32_t image, const float* src_rgba);
+/* The denoiser hand-off of main.cpp:152-184 without its host loops: the reference reads each RGBA image back, strips the
+ * alpha on the CPU (rgbaTOrgb, main.cpp:158,164,170) into OIDN's Float3 buffers, and re-expands the denoised colour to
+ * RGBA with alpha 1 before glTexSubImage2D (main.cpp:176-184).  These two do the repacking on the GPU and move W*H*3
+ * floats: rt_read_image_rgb fills an OIDN Float3 buffer, rt_write_image_rgb takes one back (alpha := 1). */
+rt_status rt_read_image_rgb(rt_ctx* ctx, uint32_t image, float* dst_rgb);
+rt_status rt_write_image_rgb(rt_ctx* ctx, uint32_t image, const float* src_rgb);
 /* Device address of an image (W*H*4 floats) for zero-copy consumers on the same GPU (RCCL reduce,
  * device-side denoisers).  No reference counterpart. */
 rt_status rt_image_device_ptr(rt_ctx* ctx, uint32_t image, void** dev_ptr);

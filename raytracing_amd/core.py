@@ -107,6 +107,18 @@ class ComputeShader:
         assert a.shape == (self.height, self.width, 4)
         self._chk(self._L.rt_write_image(self._h, image, a.ctypes.data_as(C.c_void_p)))
 
+    def get_image_rgb(self, image=0):
+        """main.cpp:157-170 (glGetTexImage + rgbaTOrgb): [H, W, 3] float32 in OIDN's Float3 layout."""
+        out = np.empty((self.height, self.width, 3), np.float32)
+        self._chk(self._L.rt_read_image_rgb(self._h, image, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_image_rgb(self, image, rgb):
+        """main.cpp:176-184: a denoised Float3 buffer back into the RGBA image, alpha 1."""
+        a = np.ascontiguousarray(rgb, np.float32)
+        assert a.shape == (self.height, self.width, 3)
+        self._chk(self._L.rt_write_image_rgb(self._h, image, a.ctypes.data_as(C.c_void_p)))
+
     def image_device_ptr(self, image=0):
         p = C.c_void_p()
         self._chk(self._L.rt_image_device_ptr(self._h, image, C.byref(p)))

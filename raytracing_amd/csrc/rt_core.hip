@@ -53,6 +53,7 @@ struct rt_ctx {
     uint32_t width = 0, height = 0;
     DevBuf img[4];
     DevBuf primTri, primHit;
+    DevBuf rgbStage;            // packed RGB staging of rt_read_image_rgb / rt_write_image_rgb
     bool primValid = false;
 
     // path state
@@ -474,6 +475,19 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     return RT_OK;
 }
 
+// RGBA32F image <-> tightly packed RGB (OIDN's Float3 layout; main.cpp:157-170 rgbaTOrgb and 176-183 on the way back)
+__global__ void k_pack_rgb(const float4* __restrict__ img, float* __restrict__ rgb, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 v = img[i];
+    rgb[3 * i] = v.x; rgb[3 * i + 1] = v.y; rgb[3 * i + 2] = v.z;
+}
+__global__ void k_unpack_rgb(float4* __restrict__ img, const float* __restrict__ rgb, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    img[i] = make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.f);
+}
+
 bool name_is(const char* a, const char* b) { return std::strcmp(a, b) == 0; }
 
 }  // namespace
@@ -516,7 +530,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->evInit) (void)hipEventDestroy(c->evInit);
     for (hipStream_t x : c->extra) if (x) (void)hipStreamDestroy(x);
     DevBuf* bufs[] = {&c->dNodes, &c->dTris, &c->dShade, &c->dShadeUV, &c->dCMat, &c->dMaterials, &c->dVertices, &c->dLights, &c->dTexDescs,
-                      &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->accum, &c->dStats};
+                      &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->accum, &c->dStats, &c->rgbStage};
     for (DevBuf* b : bufs) b->release();
     for (auto& t : c->textures) t.data.release();
     for (auto& e : c->evRing) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
@@ -634,6 +648,34 @@ rt_status rt_write_image(rt_ctx* c, uint32_t image, const float* src) {
     if (!c->img[image].p) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(c->img[image].p, src, (size_t)c->width * c->height * 16, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+rt_status rt_read_image_rgb(rt_ctx* c, uint32_t image, float* dst) {
+    if (!c) return RT_ERR_INVALID;
+    if (image > 3 || !dst) return fail(c, RT_ERR_INVALID, "image must be 0..3 and dst non-NULL");
+    if (!c->img[image].p) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = c->width * c->height;
+    rt_status s = ensure(c, c->rgbStage, (size_t)n * 12);
+    if (s) return s;
+    k_pack_rgb<<<(n + 255) / 256, 256, 0, c->stream>>>((const float4*)c->img[image].p, (float*)c->rgbStage.p, n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(dst, c->rgbStage.p, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+rt_status rt_write_image_rgb(rt_ctx* c, uint32_t image, const float* src) {
+    if (!c) return RT_ERR_INVALID;
+    if (image > 3 || !src) return fail(c, RT_ERR_INVALID, "image must be 0..3 and src non-NULL");
+    if (!c->img[image].p) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = c->width * c->height;
+    rt_status s = ensure(c, c->rgbStage, (size_t)n * 12);
+    if (s) return s;
+    HIPCHK(c, hipMemcpyAsync(c->rgbStage.p, src, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    k_unpack_rgb<<<(n + 255) / 256, 256, 0, c->stream>>>((float4*)c->img[image].p, (const float*)c->rgbStage.p, n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 rt_status rt_image_device_ptr(rt_ctx* c, uint32_t image, void** p) {

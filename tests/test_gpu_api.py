@@ -184,6 +184,25 @@ def test_write_image_and_device_pointer(scene4):
     cs.Delete()
 
 
+def test_denoiser_hand_off_rgb_round_trip(scene4):
+    """rt_read_image_rgb / rt_write_image_rgb = the reference's rgbaTOrgb read-back into OIDN's Float3 buffers and the
+    alpha-1 write-back of the denoised colour (main.cpp:152-184), repacked on the GPU."""
+    from raytracing_amd import ComputeShader
+    W, H = 70, 41                                    # not a multiple of anything
+    cs = ComputeShader()
+    setup_core(cs, scene4, W, H, 2, 3)
+    cs.dispatch()
+    for k in range(4):
+        assert np.array_equal(bits(cs.get_image_rgb(k)), bits(cs.get_image(k)[..., :3]))
+    rng = np.random.default_rng(5)
+    den = rng.random((H, W, 3), dtype=np.float32)
+    cs.set_image_rgb(0, den)
+    back = cs.get_image(0)
+    assert np.array_equal(back[..., :3], den) and (back[..., 3] == 1).all()
+    assert np.array_equal(cs.get_image_rgb(0), den)
+    cs.Delete()
+
+
 def test_camera_path_driver_writes_reference_frames(oracle_lib, models_root, tmp_path):
     """Config 5's driver (raytracing_amd/render_path.py = Renderer::Start/NextFrame/UpdateCamera): frame 0 with the
     default camera, frame f >= 1 with the orbit camera of frame f, 8-bit PPM frames as Renderer.cpp:103-124 converts them."""
