@@ -400,3 +400,25 @@ def test_tree_deeper_than_the_reference_stack(oracle_lib, mode):
     cs.dispatch()
     assert same_floats(cs.get_image(0), want2["color"]).all()
     cs.Delete()
+
+
+@pytest.mark.parametrize("scene_id,bounces", [(4, 8), (7, 16)])
+def test_headline_sample_count_bit_exact(oracle_lib, scenes, scene_id, bounces):
+    """The sample count of the headline configs (1024 spp: 32 x 32 jitter grid, strength 1/1024, cut-off 0.01/1024,
+    sixteen 64-sample passes on four streams, the ordered replay across all of them) on an image small enough for the
+    oracle: all four images bit for bit."""
+    from raytracing_amd import ComputeShader
+    sc = scenes(scene_id)
+    W, H, spp = 24, 16, 1024
+    want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, bounces, math_mode=1))
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, bounces)
+    cs.dispatch()
+    for k, name in enumerate(("color", "albedo", "normal", "depth")):
+        bad = ~same_floats(cs.get_image(k), want[name])
+        assert not bad.any(), "%s: %d floats differ" % (name, int(bad.sum()))
+    st, ost = cs.stats(), want["stats"]
+    assert st["rays_primary"] == ost["rays_primary"] == W * H * spp
+    assert st["rays_bounce"] == ost["rays_bounce"]
+    assert st["rays_shadow"] + st["rays_shadow_skipped"] == ost["rays_shadow"]
+    cs.Delete()
