@@ -422,3 +422,29 @@ def test_headline_sample_count_bit_exact(oracle_lib, scenes, scene_id, bounces):
     assert st["rays_bounce"] == ost["rays_bounce"]
     assert st["rays_shadow"] + st["rays_shadow_skipped"] == ost["rays_shadow"]
     cs.Delete()
+
+
+def test_headline_frame_windows_match_oracle(oracle_lib, scenes):
+    """The headline workload itself — scene 4, 1920x1080, 1024 spp, 8 bounces, one rt_render_frame — checked against the
+    oracle where the oracle can afford it: four 12x8-pixel windows of the full-size frame (two of the mirror spheres, the
+    floor in front of them, the horizon with sky), rendered by the oracle with the same full-size camera.  Bit for bit."""
+    from raytracing_amd import ComputeShader
+    sc = scenes(4)
+    W, H, spp, b = 1920, 1080, 1024, 8
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, b)
+    cs.dispatch()
+    got = cs.get_image(0)
+    tri, _ = cs.primary_hits()
+    kinds = set()
+    for (x0, y0) in ((160, 160), (600, 164), (1000, 60), (950, 482)):
+        x1, y1 = x0 + 12, y0 + 8
+        want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1, region=(x0, y0, x1, y1)))
+        bad = ~same_floats(got[y0:y1, x0:x1], want["color"][y0:y1, x0:x1])
+        assert not bad.any(), "window at (%d, %d): %d floats differ" % (x0, y0, int(bad.sum()))
+        assert np.array_equal(tri[y0:y1, x0:x1], want["prim_tri"][y0:y1, x0:x1])
+        kinds |= set(np.unique(sc.triangles["materialIndex"][tri[y0:y1, x0:x1][tri[y0:y1, x0:x1] >= 0]]).tolist())
+        if (tri[y0:y1, x0:x1] < 0).any():
+            kinds.add("sky")
+    assert len(kinds) >= 4, kinds          # the windows do look at different things
+    cs.Delete()
