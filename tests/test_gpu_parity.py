@@ -448,3 +448,32 @@ def test_headline_frame_windows_match_oracle(oracle_lib, scenes):
             kinds.add("sky")
     assert len(kinds) >= 4, kinds          # the windows do look at different things
     cs.Delete()
+
+
+def test_4k_orbit_frame_windows_match_oracle(oracle_lib, scenes):
+    """Config 5's frame — scene 7, 3840x2160, 1024 spp, 8 bounces, the orbit camera of frame 30 (Renderer.cpp:187-193) —
+    against the oracle in four 12x8 windows of the full-size frame: the metal object, the glass one, the diffuse one and
+    the horizon.  Bit for bit."""
+    from oracle import gltf_flatten as G
+    from raytracing_amd import ComputeShader
+    sc = scenes(7)
+    W, H, spp, b = 3840, 2160, 1024, 8
+    cam = G.orbit_camera(30)
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, b, camera=cam)
+    cs.dispatch()
+    got = cs.get_image(0)
+    tri, _ = cs.primary_hits()
+    kinds = set()
+    for (x0, y0) in ((1560, 450), (1900, 450), (2200, 450), (1900, 914)):
+        x1, y1 = x0 + 12, y0 + 8
+        want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, camera=cam, math_mode=1, region=(x0, y0, x1, y1)))
+        bad = ~same_floats(got[y0:y1, x0:x1], want["color"][y0:y1, x0:x1])
+        assert not bad.any(), "window at (%d, %d): %d floats differ" % (x0, y0, int(bad.sum()))
+        t = tri[y0:y1, x0:x1]
+        assert np.array_equal(t, want["prim_tri"][y0:y1, x0:x1])
+        kinds |= set(np.unique(sc.triangles["materialIndex"][t[t >= 0]]).tolist())
+        if (t < 0).any():
+            kinds.add("sky")
+    assert {0, 1, 2, 3, "sky"} <= kinds, kinds
+    cs.Delete()
