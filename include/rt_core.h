@@ -116,6 +116,10 @@ rt_status rt_write_image(rt_ctx* ctx, uint32_t image, const float* src_rgba);
  * floats: rt_read_image_rgb fills an OIDN Float3 buffer, rt_write_image_rgb takes one back (alpha := 1). */
 rt_status rt_read_image_rgb(rt_ctx* ctx, uint32_t image, float* dst_rgb);
 rt_status rt_write_image_rgb(rt_ctx* ctx, uint32_t image, const float* src_rgb);
+/* Replaces the read-back + 8-bit conversion of Renderer::NextFrame (Renderer.cpp:95-107) and the vertical flip of its
+ * frame copy (121-127): the colour image clamped to [0, 1], * 255, truncated to unsigned char, W*H*4 bytes, TOP row
+ * first.  Converted on the GPU; a quarter of the bytes of rt_read_image cross PCIe. */
+rt_status rt_read_frame_rgba8(rt_ctx* ctx, uint8_t* dst_rgba8, uint64_t dst_bytes /* must be W*H*4 */);
 /* Device address of an image (W*H*4 floats) for zero-copy consumers on the same GPU (RCCL reduce,
  * device-side denoisers).  No reference counterpart. */
 rt_status rt_image_device_ptr(rt_ctx* ctx, uint32_t image, void** dev_ptr);

@@ -421,17 +421,9 @@ void Renderer::Start(int /*width*/, int /*height*/, int samplesPerPixel, int max
 
 // Renderer.cpp:95-124: RGBA32F -> clamp -> *255 truncate -> vertical flip
 std::vector<uint8_t> Renderer::FrameRGBA8(rt_ctx* ctx, uint32_t width, uint32_t height) {
-    std::vector<float> floats((size_t)width * height * 4);
-    chk(ctx, rt_read_image(ctx, RT_IMAGE_COLOR, floats.data()), "rt_read_image");
-    std::vector<uint8_t> bytes(floats.size());
-    for (uint32_t y = 0; y < height; y++) {
-        uint32_t srcY = height - 1 - y;
-        for (size_t i = 0; i < (size_t)width * 4; i++) {
-            float f = floats[(size_t)srcY * width * 4 + i];
-            f = f < 0.f ? 0.f : (f > 1.f ? 1.f : f);          // std::clamp (NaN passes through and converts to 0 on x86)
-            bytes[(size_t)y * width * 4 + i] = f == f ? static_cast<unsigned char>(f * 255.f) : 0;
-        }
-    }
+    // Renderer.cpp:95-107 (+ the flip of 121-127): done by the core on the GPU, one byte per channel comes back
+    std::vector<uint8_t> bytes((size_t)width * height * 4);
+    chk(ctx, rt_read_frame_rgba8(ctx, bytes.data(), bytes.size()), "rt_read_frame_rgba8");   // fails if width x height is not the image size
     return bytes;
 }
 

@@ -488,6 +488,20 @@ __global__ void k_unpack_rgb(float4* __restrict__ img, const float* __restrict__
     img[i] = make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.f);
 }
 
+// Renderer.cpp:103-107 + the vertical flip of 121-127: clamp to [0, 1], * 255, truncating cast; top row first.
+// (A NaN passes std::clamp and converts to 0 on the reference's x86 build; here it is written as 0 explicitly.)
+__global__ void k_frame_rgba8(const float4* __restrict__ img, uchar4* __restrict__ out, uint32_t w, uint32_t h) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    const uint32_t y = i / w, x = i - y * w;
+    const float4 v = img[(size_t)(h - 1u - y) * w + x];
+    auto cv = [](float f) -> unsigned char {
+        f = f < 0.f ? 0.f : (f > 1.f ? 1.f : f);
+        return f == f ? static_cast<unsigned char>(f * 255.f) : (unsigned char)0;
+    };
+    out[i] = make_uchar4(cv(v.x), cv(v.y), cv(v.z), cv(v.w));
+}
+
 bool name_is(const char* a, const char* b) { return std::strcmp(a, b) == 0; }
 
 }  // namespace
@@ -675,6 +689,21 @@ rt_status rt_write_image_rgb(rt_ctx* c, uint32_t image, const float* src) {
     HIPCHK(c, hipMemcpyAsync(c->rgbStage.p, src, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
     k_unpack_rgb<<<(n + 255) / 256, 256, 0, c->stream>>>((float4*)c->img[image].p, (const float*)c->rgbStage.p, n);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+rt_status rt_read_frame_rgba8(rt_ctx* c, uint8_t* dst, uint64_t dst_bytes) {
+    if (!c) return RT_ERR_INVALID;
+    if (!dst) return fail(c, RT_ERR_INVALID, "dst must be non-NULL");
+    if (!c->img[0].p) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = c->width * c->height;
+    if (dst_bytes != (uint64_t)n * 4) return fail(c, RT_ERR_INVALID, "dst_bytes must be width * height * 4 of the current image size");
+    rt_status s = ensure(c, c->rgbStage, (size_t)n * 12);          // shared staging area (n * 4 bytes used here)
+    if (s) return s;
+    k_frame_rgba8<<<(n + 255) / 256, 256, 0, c->stream>>>((const float4*)c->img[0].p, (uchar4*)c->rgbStage.p, c->width, c->height);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(dst, c->rgbStage.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

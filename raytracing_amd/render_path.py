@@ -78,6 +78,8 @@ def main(argv=None):
 
     frames = range(args.first_frame, args.first_frame + args.frames)
     rays = 0
+    from concurrent.futures import ThreadPoolExecutor
+    pool, pending = ThreadPoolExecutor(max_workers=1), []
     if world > 1:
         torch.cuda.synchronize()
         dist.barrier()
@@ -96,7 +98,14 @@ def main(argv=None):
         st = cs.stats()
         rays += st["rays_primary"] + st["rays_bounce"] + st["rays_shadow"]
         if out_dir and writer:
-            write_ppm(os.path.join(out_dir, "frame_%04d.ppm" % f), S.frame_rgba8(cs))
+            # the 8-bit frame is converted on the GPU and read back here; the file is written by a worker thread while
+            # the next frame renders (the render call releases the GIL); at most two frames are held
+            if len(pending) >= 2:
+                pending.pop(0).result()
+            pending.append(pool.submit(write_ppm, os.path.join(out_dir, "frame_%04d.ppm" % f), S.frame_rgba8(cs)))
+    for fut in pending:                # frames still being written count
+        fut.result()
+    pool.shutdown()
     if world > 1:                      # (dispatch returns with the images complete)
         torch.cuda.synchronize()
         dist.barrier()

@@ -203,6 +203,30 @@ def test_denoiser_hand_off_rgb_round_trip(scene4):
     cs.Delete()
 
 
+def test_frame_rgba8_is_the_reference_conversion(scene4):
+    """rt_read_frame_rgba8 (through rth_frame_rgba8) = Renderer::NextFrame's clamp / * 255 / truncate and its vertical
+    flip (Renderer.cpp:95-127), converted on the GPU; a size that is not the image's is refused, not overrun."""
+    import ctypes as C
+    from raytracing_amd import ComputeShader, _lib
+    from raytracing_amd import scene as S
+    W, H = 90, 52
+    cs = ComputeShader()
+    setup_core(cs, scene4, W, H, 3, 4)
+    cs.dispatch()
+    img = cs.get_image(0)
+    img[5, 7] = (np.nan, -0.5, 7.0, 0.999)                     # NaN -> 0, clamps, truncation
+    cs.set_image(0, img)
+    got = S.frame_rgba8(cs)
+    f = np.where(np.isnan(img), np.float32(0), np.clip(img, np.float32(0), np.float32(1)))
+    want = (f * np.float32(255)).astype(np.uint8)[::-1]
+    assert np.array_equal(got, want)
+    assert tuple(got[H - 1 - 5, 7]) == (0, 0, 255, 254)
+    small = np.empty(16, np.uint8)
+    st = _lib.load().rt_read_frame_rgba8(cs._h, small.ctypes.data_as(C.c_void_p), C.c_uint64(small.nbytes))
+    assert st == 2                                            # RT_ERR_INVALID
+    cs.Delete()
+
+
 def test_camera_path_driver_writes_reference_frames(oracle_lib, models_root, tmp_path):
     """Config 5's driver (raytracing_amd/render_path.py = Renderer::Start/NextFrame/UpdateCamera): frame 0 with the
     default camera, frame f >= 1 with the orbit camera of frame f, 8-bit PPM frames as Renderer.cpp:103-124 converts them."""

@@ -26,6 +26,7 @@ rt_status rt_set_vec4(rt_ctx*, const char*, const float[4]) { return RT_ERR_NO_D
 rt_status rt_set_mat4(rt_ctx*, const char*, const float[16]) { return RT_ERR_NO_DEVICE; }
 rt_status rt_create_texture(rt_ctx*, const uint8_t*, uint32_t, uint32_t, uint64_t*) { return RT_ERR_NO_DEVICE; }
 rt_status rt_read_image(rt_ctx*, uint32_t, float*) { return RT_ERR_NO_DEVICE; }
+rt_status rt_read_frame_rgba8(rt_ctx*, uint8_t*, uint64_t) { return RT_ERR_NO_DEVICE; }
 }
 
 static int fails = 0;
