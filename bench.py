@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
-    ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="extra rt_set_int tuning knobs (refillIdle, dynamicFetch, dynBlocksPerCU ...)")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="extra rt_set_int tuning knobs (passStreams, refill, refillIdle, refillBlocksPerCU ... see INTEGRATION.md)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)

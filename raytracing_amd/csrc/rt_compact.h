@@ -195,8 +195,8 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
         }
     }
 
-    // Renumber the internal nodes breadth-first: any prefix of the array is then the top of the tree, which the
-    // traversal kernels keep resident in LDS (rt_trace_dyn.hip.h).  Triangle order (= visit rank) is untouched.
+    // Renumber the internal nodes breadth-first: any prefix of the array is then the top of the tree, the part every ray
+    // touches, which so stays one contiguous, cache-friendly run.  Triangle order (= visit rank) is untouched.
     {
         const size_t n = out.nodes.size();
         std::vector<int32_t> order; order.reserve(n);          // order[new] = old
