@@ -70,6 +70,7 @@ struct rt_ctx {
     // larger than the L2s, where traversal is bound by miss latency; measured +14 % on the 20 M-triangle config,
     // -15 % on the cache-resident ones), 0 = off, 1 = on
     int32_t refill = -1, refillIdle = 8, refillBlocksPerCU = 16;
+    int32_t sunKernel = 1;      // 0: the general k_shadow also for one-sun scenes (A/B knob)
     bool anyTextured = true, anyTransmissive = true;   // which k_shade variant the scene needs (set with the materials)
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
 
@@ -442,6 +443,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                     if (count) k_shadow_refill<true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, dst);
                     else k_shadow_refill<false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, dst);
                 }
+                else if (!exact && !count && F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel)
+                    k_shadow_sun<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b);
                 else launch_shadow(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
                 evEnd(e);
             }
@@ -580,6 +583,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
+    else if (name_is(name, "sunKernel")) c->sunKernel = v;
     else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 1 ? 1 : v;
     else if (name_is(name, "autoPass")) c->autoPass = v;
     else if (name_is(name, "passStreams")) c->passStreams = v < 1 ? 4 : v;      // < 1: back to the default
