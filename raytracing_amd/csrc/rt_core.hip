@@ -429,9 +429,10 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             e = evBegin(1);
             {
                 const bool many = F.numLights > RT_MAX_LIGHTS;
-                auto shadeK = c->anyTextured ? (many ? k_shade<true, true, true> : k_shade<true, true, false>)
-                            : c->anyTransmissive ? (many ? k_shade<false, true, true> : k_shade<false, true, false>)
-                                                 : (many ? k_shade<false, false, true> : k_shade<false, false, false>);
+                const bool sun1 = F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel;
+                auto shadeK = c->anyTextured ? (many ? k_shade<true, true, true, false> : k_shade<true, true, false, false>)
+                            : c->anyTransmissive ? (many ? k_shade<false, true, true, false> : sun1 ? k_shade<false, true, false, true> : k_shade<false, true, false, false>)
+                                                 : (many ? k_shade<false, false, true, false> : sun1 ? k_shade<false, false, false, true> : k_shade<false, false, false, false>);
                 shadeK<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(qcount + b), qcount + b + 1,
                                                  scount + b, (int)rBase, (int)b, iAlb, iNor, iDep, pTri, pHit, dst);
             }

@@ -545,8 +545,9 @@ __device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float a
 // result parked in `pend` until k_shadow has traced the shadow ray (453-484).
 // TEX / GLASS: the scene has a textured (or normal-mapped) material / a transmissive one.  Scenes without them run a
 // variant with those branches compiled out: fewer live registers on the common path.  MANY: more lights than travel in
-// the kernel arguments (RT_MAX_LIGHTS); otherwise every light is a scalar kernarg read.
-template <bool TEX, bool GLASS, bool MANY>
+// the kernel arguments (RT_MAX_LIGHTS); otherwise every light is a scalar kernarg read.  SUN1: exactly one light and it is
+// a sun (every BASELINE config): no light loop, no point-light branch.
+template <bool TEX, bool GLASS, bool MANY, bool SUN1>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, PathBuffers P,
                                                     const uint32_t* __restrict__ count, uint32_t* countOut,
                                                     uint32_t* shadowCountOut, int rBase, int bounce,
@@ -747,11 +748,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 }
 
                 // light loop, shader.comp:453-522 minus the shadow lineCast (k_shadow)
-                if (F.numLights == 0) logp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int l = 0; l < F.numLights; l++) {
+                if (!SUN1 && F.numLights == 0) logp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int nLightsHere = SUN1 ? 1 : F.numLights;
+                for (int l = 0; l < nLightsHere; l++) {
                     const RefLight Lg = MANY ? light_at(S, F, l) : F.lights[l];
                     float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, __uint_as_float(Lg.lightType)), L2 = make_float4(Lg.color.x, Lg.color.y, Lg.color.z, 0.f);
-                    uint32_t ltype = __float_as_uint(L1.w);
+                    const uint32_t ltype = SUN1 ? 1u : __float_as_uint(L1.w);
                     v3 dirToLight = mk(0.f, 0.f, 0.f);
                     float attenuation = 1.f;
                     bool cast = false;
