@@ -257,7 +257,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FramePa
 
 // shader.comp:453-484: the shadow lineCast of every log entry awaiting one; the entry becomes "add" (2) or "none" (0).
 // Work item i = (shadow-queue entry i / numLights, light i % numLights).
-template <bool COUNT>
+// SUN1: exactly one light and it is a sun — no point-light state is carried (fewer registers, more resident waves, which is
+// what a miss-latency-bound kernel wants) and the direction's reciprocal is computed once per thread.
+template <bool COUNT, bool SUN1>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
                                                          int bounce, int refillIdle, DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
@@ -275,6 +277,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
     float distToLight = 0.f, lim = INF;
     int kind = 1;
     int sp = 0, cur = RT_DONE;
+    v3 sunInv = mk(1.f, 1.f, 1.f);
+    bool sunPlain = true;
+    if (SUN1) {
+        const RefLight& Lg = F.lights[0];
+        d = -mk(Lg.dir.x, Lg.dir.y, Lg.dir.z);
+        sunInv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        sunPlain = ray_is_plain(mk(0.f, 0.f, 0.f), d);
+    }
 
     for (;;) {
         const unsigned long long idleMask = __ballot(!active);
@@ -291,7 +301,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                     float* wp_ = &P.contrib[((size_t)bounce * P.lightSlots + l) * P.nslots + slot].w;
                     // one light: every queued entry awaits its shadow ray (k_shade queued it for that reason), so the
                     // scattered read of the flag is not needed
-                    if (L == 1u || *wp_ == 1.f) {
+                    if (SUN1) {
+                        o = mk(rec.x, rec.y, rec.z);
+                        wptr = wp_;
+                        if (!(sunPlain && ray_is_plain(o, mk(1.f, 1.f, 1.f)))) {
+                            bool oc = occluded_fast<COUNT, false>(S, o, d, 1, mk(0.f, 0.f, 0.f), 0.f, stk, nNodes, nTris);
+                            *wptr = oc ? 0.f : 2.f;
+                        } else {
+                            float te;
+                            if (COUNT) nNodes++;
+                            if (!slab<true>(o, sunInv, S.rootLo, S.rootHi, &te)) {
+                                *wptr = 2.f;
+                            } else {
+                                R = make_pairs(o, sunInv);
+                                occ = false; sp = 0; cur = S.rootChild;
+                                active = true;
+                            }
+                        }
+                    } else if (L == 1u || *wp_ == 1.f) {
                         o = mk(rec.x, rec.y, rec.z); shadeLoc = mk(0.f, 0.f, 0.f);
                         if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; shadeLoc = mk(h4.x, h4.y, h4.z); }
                         float4 L0, L1;
@@ -343,8 +370,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                 if (COUNT) nNodes++;
                 float te0, tx0, te1, tx1;
                 slab_pair(R, n0, n1, n2, te0, tx0, te1, tx1);
-                bool p0 = tx0 >= te0 && tx0 >= 0.0f && !(te0 > lim);
-                bool p1 = tx1 >= te1 && tx1 >= 0.0f && !(te1 > lim);
+                bool p0 = tx0 >= te0 && tx0 >= 0.0f && (SUN1 || !(te0 > lim));
+                bool p1 = tx1 >= te1 && tx1 >= 0.0f && (SUN1 || !(te1 > lim));
                 int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
                 if (p0 && p1) {      // nearer box first: an occluder, if any, tends to be found sooner
                     bool swap = te1 < te0;
@@ -363,7 +390,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                     if (COUNT) nTris++;
                     float t;
                     if (tri_t(tp[3 * k], tp[3 * k + 1], tp[3 * k + 2], o, d, &t)) {
-                        if (kind == 1) occ = true;
+                        if (SUN1 || kind == 1) occ = true;
                         else { v3 h = o + d * t; v3 dl = h - shadeLoc; if (sqrtf(dot3(dl, dl)) < distToLight) occ = true; }
                     }
                 }
