@@ -68,6 +68,20 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// slab_pair with the ray kept as six scalars instead of six register pairs (the persistent kernels hold a ray's state
+// across refills, and resident waves are what they are short of): the same (bound - o) * inv per component.
+__device__ __forceinline__ void slab_pair_s(v3 o, v3 inv, float4 n0, float4 n1, float4 n2,
+                                            float& te0, float& tx0, float& te1, float& tx1) {
+    const float ax = (n0.x - o.x) * inv.x, ay = (n0.y - o.y) * inv.y, az = (n0.z - o.z) * inv.z;
+    const float bx = (n0.w - o.x) * inv.x, by = (n1.x - o.y) * inv.y, bz = (n1.y - o.z) * inv.z;
+    const float cx = (n1.z - o.x) * inv.x, cy = (n1.w - o.y) * inv.y, cz = (n2.x - o.z) * inv.z;
+    const float dx = (n2.y - o.x) * inv.x, dy = (n2.z - o.y) * inv.y, dz = (n2.w - o.z) * inv.z;
+    te0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    tx0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    te1 = fmaxf(fmaxf(fminf(cx, dx), fminf(cy, dy)), fminf(cz, dz));
+    tx1 = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fmaxf(cz, dz));
+}
+
 // Closest hit == lineCast (shader.comp:243-290) for the rays of `queue` (PRIMARY: the camera rays of all slots).
 //
 // Ray set-up (fetch, 1/d, root box) is done for a whole 64-ray group at a time with every lane of the wave working,
@@ -76,7 +90,7 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
 // as expensive as a full wave's set-up.)
 #define RT_POOL_WORDS 10     // o.xyz, d.xyz, 1/d.xyz, queue entry
 template <bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
+__global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
                                                          const float4* __restrict__ rays, const uint32_t* __restrict__ count,
                                                          int rBase, uint32_t rayCount, int refillIdle,
                                                          DeviceStats* stats) {
@@ -94,7 +108,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FramePa
     bool active = false;
     uint32_t slot = 0;
     v3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
-    RayPairs R = make_pairs(o, o);
+    v3 rinv = mk(1.f, 1.f, 1.f);
     float bestT = INF, bestDist = 3.40282347e+38f, lim = INF;
     int bestIdx = -1, bestRef = -1;
     int sp = 0, cur = RT_DONE;
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FramePa
                     closest_hit<false, COUNT, false>(S, o, d, stk, best, nNodes, nTris);
                     P.hit[slot] = make_float2(best.t, __int_as_float(best.ref));
                 } else {
-                    R = make_pairs(o, inv);
+                    rinv = inv;
                     bestT = INF; bestDist = 3.40282347e+38f; lim = INF; bestIdx = -1; bestRef = -1;
                     sp = 0; cur = S.rootChild;
                     if (COUNT) steps0 = nNodes + nTris;
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_refill(SceneView S, FramePa
                 float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 if (COUNT) nNodes++;
                 float te0, tx0, te1, tx1;
-                slab_pair(R, n0, n1, n2, te0, tx0, te1, tx1);
+                slab_pair_s(o, rinv, n0, n1, n2, te0, tx0, te1, tx1);
                 bool p0 = tx0 >= te0 && tx0 >= 0.0f && !(te0 > lim);
                 bool p1 = tx1 >= te1 && tx1 >= 0.0f && !(te1 > lim);
                 int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
     bool active = false, occ = false;
     float* wptr = nullptr;
     v3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f), shadeLoc = mk(0.f, 0.f, 0.f);
-    RayPairs R = make_pairs(o, o);
+    v3 rinv = mk(1.f, 1.f, 1.f);
     float distToLight = 0.f, lim = INF;
     int kind = 1;
     int sp = 0, cur = RT_DONE;
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                             if (!slab<true>(o, sunInv, S.rootLo, S.rootHi, &te)) {
                                 *wptr = 2.f;
                             } else {
-                                R = make_pairs(o, sunInv);
+                                rinv = sunInv;
                                 occ = false; sp = 0; cur = S.rootChild;
                                 active = true;
                             }
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                             if (!slab<true>(o, inv, S.rootLo, S.rootHi, &te)) {
                                 *wptr = 2.f;
                             } else {
-                                R = make_pairs(o, inv);
+                                rinv = inv;
                                 lim = (kind == 0) ? (distToLight + distToLight * 1e-3f + S.cullAbs * 4.0f) : INF;
                                 occ = false; sp = 0; cur = S.rootChild;
                                 active = true;
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                 float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 if (COUNT) nNodes++;
                 float te0, tx0, te1, tx1;
-                slab_pair(R, n0, n1, n2, te0, tx0, te1, tx1);
+                slab_pair_s(o, rinv, n0, n1, n2, te0, tx0, te1, tx1);
                 bool p0 = tx0 >= te0 && tx0 >= 0.0f && (SUN1 || !(te0 > lim));
                 bool p1 = tx1 >= te1 && tx1 >= 0.0f && (SUN1 || !(te1 > lim));
                 int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
