@@ -70,6 +70,13 @@ struct rt_ctx {
     // larger than the L2s, where traversal is bound by miss latency; measured +14 % on the 20 M-triangle config,
     // -15 % on the cache-resident ones), 0 = off, 1 = on
     int32_t refill = -1, refillIdle = 8, refillBlocksPerCU = 16;
+    // refill = -1 on a cache-resident scene: which traversal kernels are faster depends on how uneven the rays of the
+    // scene are (scene 7: +5 % with refill, scene 4: -2 %), so the first two sizeable frames after a scene upload are
+    // rendered one way each and the faster way (rays per millisecond) is kept.  Images do not depend on the choice.
+    uint64_t allocations = 0;   // hipMalloc calls so far (a frame that allocated is not a timing sample)
+    int tuneState = 0;          // 0: next sizeable frame samples the batch kernels, 1: the refill kernels, 2: decided
+    double tuneRate[2] = {0.0, 0.0};
+    bool tuneRefill = false;
     int32_t sunKernel = 1;      // 0: the general k_shadow also for one-sun scenes (A/B knob)
     bool anyTextured = true, anyTransmissive = true;   // which k_shade variant the scene needs (set with the materials)
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
@@ -99,6 +106,7 @@ rt_status ensure(rt_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     HIPCHK(c, hipMalloc(&b.p, bytes));
     b.bytes = bytes;
+    c->allocations++;
     return RT_OK;
 }
 
@@ -130,6 +138,7 @@ rt_status sync_scene(rt_ctx* c) {
         if ((s = upload(c, c->dVertices, V.data(), V.size()))) return s;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->sceneDirty = false;
+        c->tuneState = 0; c->tuneRefill = false;
     }
     if (c->materialsDirty) {
         const auto& M = c->slotHost[RT_SLOT_MATERIALS];
@@ -275,6 +284,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     if (s) return s;
     if ((uint64_t)c->numLights > c->nLights) return fail(c, RT_ERR_INVALID, "numLights exceeds the light buffer (slot 5)");
     auto t0 = std::chrono::steady_clock::now();
+    const uint64_t allocationsBefore = c->allocations;
 
     FrameParams F;
     std::memset(&F, 0, sizeof F);
@@ -364,7 +374,9 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
     const size_t bvhBytes = c->cs.nodes.size() * sizeof(CNode) + c->cs.tris.size() * sizeof(CTri);
-    const bool refill = !exact && (c->refill > 0 || (c->refill < 0 && bvhBytes > (size_t)64 << 20));
+    const bool bigScene = bvhBytes > (size_t)64 << 20;
+    const bool tuning = !exact && !count && c->refill < 0 && !bigScene;
+    const bool refill = !exact && (c->refill > 0 || (c->refill < 0 && (bigScene || (tuning && (c->tuneState == 1 || (c->tuneState == 2 && c->tuneRefill))))));
     const int refillIdle = std::min(64, std::max(1, (int)c->refillIdle));
     hipStream_t streams[rt_ctx::kMaxSets];
     streams[0] = c->stream;
@@ -471,6 +483,13 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.rays_primary = hs.rays_primary; c->stats.rays_bounce = hs.rays_bounce; c->stats.rays_shadow = hs.rays_shadow;
     c->stats.rays_shadow_skipped = hs.rays_shadow_skipped; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
     c->stats.ms_total = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (tuning && c->tuneState < 2) {
+        const double rays = (double)(hs.rays_primary + hs.rays_bounce + hs.rays_shadow);
+        if (rays >= 5.0e7 && c->stats.ms_total > 0.0 && c->allocations == allocationsBefore) {          // a frame large enough to be a measurement
+            c->tuneRate[c->tuneState] = rays / c->stats.ms_total;
+            if (++c->tuneState == 2) c->tuneRefill = c->tuneRate[1] > 1.015 * c->tuneRate[0];
+        }
+    }
     c->stats.shadow_node_visits = hs.shadow_node_visits; c->stats.shadow_tri_tests = hs.shadow_tri_tests;
     c->stats.max_ray_steps = hs.max_ray_steps;
     c->stats.bounce_node_visits = hs.bounce_node_visits; c->stats.bounce_tri_tests = hs.bounce_tri_tests;
