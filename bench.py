@@ -40,7 +40,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=3)      # frame 1 allocates, frames 2 and 3 are the library's batch / refill trial (rt_core.h, refill)
+    ap.add_argument("--warmup", type=int, default=5)      # frame 1 allocates, frames 2 to 5 are the library's trial of its traversal kernels (rt_core.h, refill)
     # workload = a BASELINE.json config; c2 is the headline (the default), the others are reported for context
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     # development overrides (a run with any of these set is labelled in config and is not the headline)

@@ -66,17 +66,16 @@ struct rt_ctx {
     hipStream_t extra[kMaxSets] = {};     // streams of sets 1.. (set 0 uses `stream`)
     hipEvent_t evResolve[kMaxSets] = {}, evInit = nullptr;
     int32_t passStreams = 4, autoPass = 1;
-    // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill -1 = automatic (on when the compact BVH is far
-    // larger than the L2s, where traversal is bound by miss latency; measured +14 % on the 20 M-triangle config,
-    // -15 % on the cache-resident ones), 0 = off, 1 = on
+    // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill 0 = never, 1 = always, -1 = chosen per scene.
     int32_t refill = -1, refillIdle = 8, refillBlocksPerCU = 16;
-    // refill = -1 on a cache-resident scene: which traversal kernels are faster depends on how uneven the rays of the
-    // scene are (scene 7: +5 % with refill, scene 4: -2 %), so the first two sizeable frames after a scene upload are
-    // rendered one way each and the faster way (rays per millisecond) is kept.  Images do not depend on the choice.
+    // refill = -1: which traversal kernels are faster depends on the scene, and not the same way for closest-hit and
+    // shadow rays (scene 7: closest hit +14 % with refill, one-sun shadow rays -5 %; scene 4: batch for both; the
+    // 20 M-triangle field: refill for both), so the first four sizeable frames after a scene upload are rendered with
+    // the four combinations and the fastest (rays per millisecond) is kept.  Images do not depend on the choice.
     uint64_t allocations = 0;   // hipMalloc calls so far (a frame that allocated is not a timing sample)
-    int tuneState = 0;          // 0: next sizeable frame samples the batch kernels, 1: the refill kernels, 2: decided
-    double tuneRate[2] = {0.0, 0.0};
-    bool tuneRefill = false;
+    int tuneState = 0;          // 0..3: the next sizeable frame samples combination kTuneTrial[tuneState]; 4: decided
+    double tuneRate[4] = {0.0, 0.0, 0.0, 0.0};
+    int tuneChoice = 0;         // bit 0: refill kernel for closest-hit rays, bit 1: for shadow rays
     int32_t sunKernel = 1;      // 0: the general k_shadow also for one-sun scenes (A/B knob)
     bool anyTextured = true, anyTransmissive = true;   // which k_shade variant the scene needs (set with the materials)
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
@@ -138,7 +137,7 @@ rt_status sync_scene(rt_ctx* c) {
         if ((s = upload(c, c->dVertices, V.data(), V.size()))) return s;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->sceneDirty = false;
-        c->tuneState = 0; c->tuneRefill = false;
+        c->tuneState = 0; c->tuneChoice = 0;
     }
     if (c->materialsDirty) {
         const auto& M = c->slotHost[RT_SLOT_MATERIALS];
@@ -375,8 +374,14 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
     const size_t bvhBytes = c->cs.nodes.size() * sizeof(CNode) + c->cs.tris.size() * sizeof(CTri);
     const bool bigScene = bvhBytes > (size_t)64 << 20;
-    const bool tuning = !exact && !count && c->refill < 0 && !bigScene;
-    const bool refill = !exact && (c->refill > 0 || (c->refill < 0 && (bigScene || (tuning && (c->tuneState == 1 || (c->tuneState == 2 && c->tuneRefill))))));
+    // Which traversal kernels: bit 0 = refill kernel for closest-hit rays, bit 1 = for shadow rays.
+    static const int kTuneTrial[4] = {0, 3, 1, 2};
+    const int comboDefault = bigScene ? 3 : 0;      // until measured: refill where traversal is bound by miss latency
+    const bool trial = !exact && !count && c->refill < 0 && c->tuneState < 4 &&
+                       (double)w * (double)h * (double)(r1 - r0) >= 2.5e7;      // a frame large enough to be a measurement
+    const int combo = exact ? 0 : c->refill > 0 ? 3 : c->refill == 0 ? 0 : c->tuneState >= 4 ? c->tuneChoice
+                    : trial ? kTuneTrial[c->tuneState] : comboDefault;
+    const bool refillExtend = (combo & 1) != 0, refillShadow = (combo & 2) != 0;
     const int refillIdle = std::min(64, std::max(1, (int)c->refillIdle));
     hipStream_t streams[rt_ctx::kMaxSets];
     streams[0] = c->stream;
@@ -430,7 +435,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         for (uint32_t b = 0; b < maxB; b++) {
             const float4* qin = b == 0 ? nullptr : P.ray[b & 1];       // bounce 0: entry i is slot i, camera rays are regenerated
             rt_ctx::EvPair* e = evBegin(0);
-            if (refill && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
+            if (refillExtend && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
                 const dim3 rg(refill_blocks(c, Pp.nslots));
                 if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
                 else k_extend_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
@@ -451,7 +456,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             evEnd(e);
             if (F.numLights > 0) {
                 e = evBegin(2);
-                if (refill) {
+                if (refillShadow) {
                     const dim3 rg(refill_blocks(c, Pp.nslots));
                     const bool sun1r = F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel;
                     if (count) k_shadow_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, dst);
@@ -483,11 +488,19 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.rays_primary = hs.rays_primary; c->stats.rays_bounce = hs.rays_bounce; c->stats.rays_shadow = hs.rays_shadow;
     c->stats.rays_shadow_skipped = hs.rays_shadow_skipped; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
     c->stats.ms_total = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    if (tuning && c->tuneState < 2) {
+    if (trial) {
         const double rays = (double)(hs.rays_primary + hs.rays_bounce + hs.rays_shadow);
-        if (rays >= 5.0e7 && c->stats.ms_total > 0.0 && c->allocations == allocationsBefore) {          // a frame large enough to be a measurement
+        if (rays >= 5.0e7 && c->stats.ms_total > 0.0 && c->allocations == allocationsBefore) {
             c->tuneRate[c->tuneState] = rays / c->stats.ms_total;
-            if (++c->tuneState == 2) c->tuneRefill = c->tuneRate[1] > 1.015 * c->tuneRate[0];
+            if (++c->tuneState == 4) {
+                // trial 0 ran the default of a cache-resident scene, trial 1 that of a large one: another combination
+                // replaces the scene's default only if it is clearly (1.5 %) faster
+                const int defTrial = bigScene ? 1 : 0;
+                int best = defTrial;
+                for (int t = 0; t < 4; t++) if (c->tuneRate[t] > c->tuneRate[best]) best = t;
+                if (c->tuneRate[best] <= 1.015 * c->tuneRate[defTrial]) best = defTrial;
+                c->tuneChoice = kTuneTrial[best];
+            }
         }
     }
     c->stats.shadow_node_visits = hs.shadow_node_visits; c->stats.shadow_tri_tests = hs.shadow_tri_tests;

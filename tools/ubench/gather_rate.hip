@@ -11,7 +11,11 @@
 // MODE 0: 4 x dwordx4 from one 64-B record per lane (a node fetch)   MODE 1: 1 x dwordx4   MODE 2: 1 x dword
 // MODE 3: 4 x ds_read_b128 from an LDS copy (64-B records)           MODE 4: 2 x dwordx4 (32-B record)
 // MODE 7: 4 x dwordx4, the 4 lanes of a quad reading the 4 words of one 64-B record (coalesced 64-B requests)
+// MODE 8: MODE 0 with a 32-bit byte offset from a wave-uniform base (global_load ... v_off, s[base])   MODE 9: MODE 0 as raw buffer loads
+// MODE 10: MODE 0 with the first word's load completed (s_waitcnt) before the other three are issued (do in-flight misses to one line merge?)
 // MODE 5: 8 x dwordx4 from one 128-B record per lane (a whole cache line: a 4-wide node)   MODE 6: 3 x dwordx4 at 48-B stride (a triangle record)
+__device__ __forceinline__ float sum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(const float4* __restrict__ table, uint32_t nrec, int iters, int activeLanes, int uniform, float* out) {
     __shared__ float4 lds[MODE == 3 ? 2048 * 4 : 1];
@@ -25,18 +29,27 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ table, uint3
             uint32_t r = uniform ? (uint32_t)(i * 7919) % nrec : (x >> 8) % nrec;
             if (MODE == 3) r &= 2047;
             float4 a, b, c, d;
-            if (MODE == 0) { const float4* p = table + (size_t)r * 4; a = p[0]; b = p[1]; c = p[2]; d = p[3]; acc += a.x + b.y + c.z + d.w; }
-            else if (MODE == 1) { a = table[(size_t)r * 4]; acc += a.x + a.w; }
+            if (MODE == 0) { const float4* p = table + (size_t)r * 4; a = p[0]; b = p[1]; c = p[2]; d = p[3]; acc += sum4(a) + sum4(b) + sum4(c) + sum4(d); }
+            else if (MODE == 1) { a = table[(size_t)r * 4]; acc += sum4(a); }
             else if (MODE == 2) { acc += reinterpret_cast<const float*>(table)[(size_t)r * 16]; }
-            else if (MODE == 3) { const float4* p = lds + r * 4; a = p[0]; b = p[1]; c = p[2]; d = p[3]; acc += a.x + b.y + c.z + d.w; }
-            else if (MODE == 4) { const float4* p = table + (size_t)r * 4; a = p[0]; b = p[1]; acc += a.x + b.y; }
-            else if (MODE == 5) { const float4* p = table + (size_t)(r >> 1) * 8; a = p[0]; b = p[1]; c = p[2]; d = p[3]; float4 e = p[4], f = p[5], g = p[6], h = p[7]; acc += a.x + b.y + c.z + d.w + e.x + f.y + g.z + h.w; }
+            else if (MODE == 3) { const float4* p = lds + r * 4; a = p[0]; b = p[1]; c = p[2]; d = p[3]; acc += sum4(a) + sum4(b) + sum4(c) + sum4(d); }
+            else if (MODE == 4) { const float4* p = table + (size_t)r * 4; a = p[0]; b = p[1]; acc += sum4(a) + sum4(b); }
+            else if (MODE == 5) { const float4* p = table + (size_t)(r >> 1) * 8; a = p[0]; b = p[1]; c = p[2]; d = p[3]; float4 e = p[4], f = p[5], g = p[6], h = p[7]; acc += sum4(a) + sum4(b) + sum4(c) + sum4(d) + sum4(e) + sum4(f) + sum4(g) + sum4(h); }
             else if (MODE == 7) {   // quad-cooperative: the 4 lanes of a quad fetch the four 16-B words of ONE 64-B record per instruction
                 uint32_t q = lane & 3u;
                 uint32_t r0 = __shfl(r, (lane & ~3u) + 0, 64), r1 = __shfl(r, (lane & ~3u) + 1, 64), r2 = __shfl(r, (lane & ~3u) + 2, 64), r3 = __shfl(r, (lane & ~3u) + 3, 64);
                 a = table[(size_t)r0 * 4 + q]; b = table[(size_t)r1 * 4 + q]; c = table[(size_t)r2 * 4 + q]; d = table[(size_t)r3 * 4 + q];
-                acc += a.x + b.y + c.z + d.w; }
-            else if (MODE == 6) { const float4* p = table + (size_t)r * 3; a = p[0]; b = p[1]; c = p[2]; acc += a.x + b.y + c.z; }
+                acc += sum4(a) + sum4(b) + sum4(c) + sum4(d); }
+            else if (MODE == 8) { const char* base = reinterpret_cast<const char*>(table); uint32_t off = r * 64u;
+                a = *reinterpret_cast<const float4*>(base + off); b = *reinterpret_cast<const float4*>(base + off + 16);
+                c = *reinterpret_cast<const float4*>(base + off + 32); d = *reinterpret_cast<const float4*>(base + off + 48); acc += sum4(a) + sum4(b) + sum4(c) + sum4(d); }
+            else if (MODE == 9) { __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(table), 0, (int)(nrec * 64u), 0x00020000);
+                uint32_t off = r * 64u;
+                auto ld = [&](uint32_t o) { auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + o), 0, 0); float4 f; __builtin_memcpy(&f, &v, 16); return f; };
+                a = ld(0); b = ld(16); c = ld(32); d = ld(48); acc += sum4(a) + sum4(b) + sum4(c) + sum4(d); }
+            else if (MODE == 10) { const float4* p = table + (size_t)r * 4; a = p[0]; asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) :: "memory");
+                b = p[1]; c = p[2]; d = p[3]; acc += sum4(a) + sum4(b) + sum4(c) + sum4(d); }
+            else if (MODE == 6) { const float4* p = table + (size_t)r * 3; a = p[0]; b = p[1]; c = p[2]; acc += sum4(a) + sum4(b) + sum4(c); }
             // dependent chain like a traversal: next index depends on the data
             x += (uint32_t)(acc != 12345.678f);
         }
@@ -77,6 +90,9 @@ int main() {
     run<5>("8 x dwordx4 (128-B record)", table, nrec, out, 8);
     run<6>("3 x dwordx4 (48-B stride)", table, nrec, out, 3);
     run<7>("4 x dwordx4 quad-cooperative", table, nrec, out, 4);
+    run<10>("1 + wait + 3 x dwordx4", table, nrec, out, 4);
+    run<8>("4 x dwordx4 saddr + voffset", table, nrec, out, 4);
+    run<9>("4 x buffer_load_dwordx4", table, nrec, out, 4);
     run<3>("4 x ds_read_b128", table, nrec, out, 4);
     return 0;
 }
