@@ -33,7 +33,8 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 S_NODE, S_TRI = 64, 48         # bytes per compact node / triangle record
 CU_CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock
-VMEM_LANE_LOADS_PER_CLK = 1.43 # 1 / 0.7 CU-cycles per active lane and load instruction (tools/ubench/gather_rate.hip)
+VMEM_LANE_LOADS_PER_CLK = 1.36 # 64 lanes x 4 loads / 188 CU-cycles: a 64-B record per lane, random, L2-resident (tools/ubench/gather_rate.hip)
+VMEM_CYCLES_PER_WAVE_LOAD = 17.0  # floor per wave-level load instruction, whatever its width or the number of active lanes (same source)
 
 
 def parse():
@@ -249,9 +250,10 @@ def main():
                     "kernel_ms_per_step": {k: round(agg[k] / args.steps, 2) for k in ("ms_extend", "ms_shade", "ms_shadow")},
                     "note": "bundled scenes are cache-resident (<= 13 MB): there the binding limit is the CU vector-memory/VALU path and "
                             "the HBM fraction is the contract's sanity figure (BASELINE.md); c4 is the HBM-bound configuration"}
-        # The limit that binds a cache-resident scene: per-lane load instructions through the CU's
-        # vector-memory path.  tools/ubench/gather_rate.hip measures 0.7 CU-cycles per active lane and load
-        # instruction for random gathers of L2-resident records (>= 16 active lanes) = 1.43 lane-loads per CU-clock.
+        # The limit that binds a cache-resident scene: load instructions through the CU's vector-memory
+        # path.  tools/ubench/gather_rate.hip: four dwordx4 gathers of a random L2-resident 64-B record per lane cost
+        # 188 CU-cycles per wave with all 64 lanes active = 1.36 lane-loads per CU-clock, and never less than 17
+        # CU-cycles per wave-level instruction however few lanes are active.
         lane_loads_per_ray = (4 * c["node_visits"] + 3 * c["tri_tests"]) / max(1, ext_rays_c)   # 64-B node = 4 x dwordx4, 48-B triangle = 3 loads
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         ext_s = ex["ms_extend"] * 1e-3
@@ -259,8 +261,13 @@ def main():
         roofline["vmem_path"] = {"achieved": round(ll_rate, 3), "peak": VMEM_LANE_LOADS_PER_CLK, "unit": "lane-loads per CU-clock",
                                  "frac": round(ll_rate / VMEM_LANE_LOADS_PER_CLK, 3), "lane_loads_per_ray": round(lane_loads_per_ray, 1),
                                  "cus": cus, "clock_hz": CU_CLOCK_HZ,
-                                 "note": "k_extend, exclusive frame; peak = random-gather rate of tools/ubench/gather_rate.hip at the "
-                                         "nominal 2.4 GHz (coherent camera rays coalesce and run above the per-lane random rate)"}
+                                 "note": "k_extend, exclusive frame; peak = random-gather rate of tools/ubench/gather_rate.hip with all 64 "
+                                         "lanes active, at the nominal 2.4 GHz (coherent camera rays coalesce and run above the per-lane random rate)"}
+        if c["wave_node_steps"] and c["rays_bounce"]:
+            wave_loads = (4 * c["wave_node_steps"] + 3 * c["wave_tri_steps"]) * (ex["rays_bounce"] / c["rays_bounce"])
+            roofline["vmem_path"]["bounce_wave_load_floor_ms_per_frame"] = round(wave_loads * VMEM_CYCLES_PER_WAVE_LOAD / (cus * CU_CLOCK_HZ) * 1e3, 2)
+            roofline["vmem_path"]["floor_note"] = ("wave-level load instructions of the bounce rays' k_extend launches (instrumented pass, scaled to the "
+                                                   "frame) x 17 CU-cycles each: what those launches cost at the measured issue floor alone")
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             try:
