@@ -67,7 +67,7 @@ struct rt_ctx {
     hipEvent_t evResolve[kMaxSets] = {}, evInit = nullptr;
     int32_t passStreams = 4, autoPass = 1;
     // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill 0 = never, 1 = always, -1 = chosen per scene.
-    int32_t refill = -1, refillIdle = 8, refillBlocksPerCU = 16;
+    int32_t refill = -1, refillIdle = 8, refillBlocksPerCU = 0;   // refillBlocksPerCU 0 = automatic (refill_blocks)
     // refill = -1: which traversal kernels are faster depends on the scene, and not the same way for closest-hit and
     // shadow rays (scene 7: closest hit +14 % with refill, one-sun shadow rays -5 %; scene 4: batch for both; the
     // 20 M-triangle field: refill for both), so the first four sizeable frames after a scene upload are rendered with
@@ -212,9 +212,13 @@ uint32_t trace_blocks(rt_ctx* c, uint32_t nslots) {
     uint32_t persistent = (uint32_t)c->numCUs * (uint32_t)c->blocksPerCU;
     return slotBlocks < persistent ? slotBlocks : persistent;
 }
-uint32_t refill_blocks(rt_ctx* c, uint32_t nItems) {      // persistent grid: what is resident at once
+// Persistent grid of the refill kernels.  Six workgroups per CU are resident at once (80 registers: 6 waves per SIMD) and
+// a kernel running by itself is fastest with exactly those; when passes overlap on several streams, four per CU leave
+// room for the other streams' kernels and the frame is faster (C3 -5 %, C5 -7 %, C4 -4 % against 16; measured 2..16).
+uint32_t refill_blocks(rt_ctx* c, uint32_t nItems, int nSets) {
     uint32_t itemBlocks = (nItems + RT_BLOCK - 1) / RT_BLOCK;
-    uint32_t most = (uint32_t)c->numCUs * (uint32_t)std::max(1, (int)c->refillBlocksPerCU);
+    const int perCU = c->refillBlocksPerCU > 0 ? (int)c->refillBlocksPerCU : (nSets > 1 ? 4 : 6);
+    uint32_t most = (uint32_t)c->numCUs * (uint32_t)perCU;
     return std::max(1u, itemBlocks < most ? itemBlocks : most);
 }
 uint32_t overflow_depth(rt_ctx* c) {
@@ -436,7 +440,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             const float4* qin = b == 0 ? nullptr : P.ray[b & 1];       // bounce 0: entry i is slot i, camera rays are regenerated
             rt_ctx::EvPair* e = evBegin(0);
             if (refillExtend && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
-                const dim3 rg(refill_blocks(c, Pp.nslots));
+                const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
                 if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
                 else k_extend_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
             }
@@ -457,7 +461,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             if (F.numLights > 0) {
                 e = evBegin(2);
                 if (refillShadow) {
-                    const dim3 rg(refill_blocks(c, Pp.nslots));
+                    const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
                     const bool sun1r = F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel;
                     if (count) k_shadow_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, dst);
                     else if (sun1r) k_shadow_refill<false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, dst);
@@ -619,7 +623,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
     else if (name_is(name, "sunKernel")) c->sunKernel = v;
-    else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 1 ? 1 : v;
+    else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 0 ? 0 : v;
     else if (name_is(name, "autoPass")) c->autoPass = v;
     else if (name_is(name, "passStreams")) c->passStreams = v < 1 ? 4 : v;      // < 1: back to the default
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
