@@ -79,7 +79,8 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * sum is still replayed in sample order, so results do not depend on it), refill (-1 automatic / 0 / 1: persistent
  * traversal waves that hand finished lanes new rays; automatic = the first four sizeable frames after a scene upload
  * are rendered with the four combinations (refill or not, for closest-hit and for shadow rays) and the fastest is kept;
- * until then BVHs far larger than the L2s use them and others do not), refillIdle, refillBlocksPerCU. */
+ * until then BVHs far larger than the L2s use them and others do not), refillIdle, refillNodeMin,
+ * refillBlocksPerCU. */
 rt_status rt_set_int(rt_ctx* ctx, const char* name, int32_t v);
 rt_status rt_set_float(rt_ctx* ctx, const char* name, float v);
 rt_status rt_set_vec2(rt_ctx* ctx, const char* name, const float v[2]);

@@ -67,7 +67,7 @@ struct rt_ctx {
     hipEvent_t evResolve[kMaxSets] = {}, evInit = nullptr;
     int32_t passStreams = 4, autoPass = 1;
     // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill 0 = never, 1 = always, -1 = chosen per scene.
-    int32_t refill = -1, refillIdle = 8, refillBlocksPerCU = 0;   // refillBlocksPerCU 0 = automatic (refill_blocks)
+    int32_t refill = -1, refillIdle = 8, refillNodeMin = 28, refillBlocksPerCU = 0;   // refillBlocksPerCU 0 = automatic (refill_blocks)
     // refill = -1: which traversal kernels are faster depends on the scene, and not the same way for closest-hit and
     // shadow rays (scene 7: closest hit +14 % with refill, one-sun shadow rays -5 %; scene 4: batch for both; the
     // 20 M-triangle field: refill for both), so the first four sizeable frames after a scene upload are rendered with
@@ -387,6 +387,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                     : trial ? kTuneTrial[c->tuneState] : comboDefault;
     const bool refillExtend = (combo & 1) != 0, refillShadow = (combo & 2) != 0;
     const int refillIdle = std::min(64, std::max(1, (int)c->refillIdle));
+    const int refillNodeMin = std::min(64, std::max(1, (int)c->refillNodeMin));
     hipStream_t streams[rt_ctx::kMaxSets];
     streams[0] = c->stream;
     for (int k = 1; k < rt_ctx::kMaxSets; k++) streams[k] = c->extra[k];
@@ -441,8 +442,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             rt_ctx::EvPair* e = evBegin(0);
             if (refillExtend && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
                 const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
-                if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
-                else k_extend_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, dst);
+                if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
+                else k_extend_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
             }
             else if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const float4*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
             else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
@@ -622,6 +623,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
+    else if (name_is(name, "refillNodeMin")) c->refillNodeMin = v;
     else if (name_is(name, "sunKernel")) c->sunKernel = v;
     else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 0 ? 0 : v;
     else if (name_is(name, "autoPass")) c->autoPass = v;
