@@ -464,9 +464,9 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                 if (refillShadow) {
                     const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
                     const bool sun1r = F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel;
-                    if (count) k_shadow_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, dst);
-                    else if (sun1r) k_shadow_refill<false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, dst);
-                    else k_shadow_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, dst);
+                    if (count) k_shadow_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
+                    else if (sun1r) k_shadow_refill<false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
+                    else k_shadow_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
                 }
                 else if (!exact && !count && F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel)
                     k_shadow_sun<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b);

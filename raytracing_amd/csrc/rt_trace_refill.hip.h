@@ -311,7 +311,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
 // what a miss-latency-bound kernel wants) and the direction's reciprocal is computed once per thread.
 template <bool COUNT, bool SUN1>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
-                                                         int bounce, int refillIdle, DeviceStats* stats) {
+                                                         int bounce, int refillIdle, int nodeMin, DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
     const Stack stk = make_stack(lds, P);
     const uint32_t L = (uint32_t)F.numLights;
@@ -326,7 +326,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
     v3 rinv = mk(1.f, 1.f, 1.f);
     float distToLight = 0.f, lim = INF;
     int kind = 1;
-    int sp = 0, cur = RT_DONE;
+    int sp = 0, cur = RT_DONE, pend = RT_DONE;     // pend: a leaf reached but not tested yet
+    auto popS = [&]() { cur = sp > 0 ? (int)stk.pop(sp).x : RT_DONE; };
     v3 sunInv = mk(1.f, 1.f, 1.f);
     bool sunPlain = true;
     if (SUN1) {
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                                 *wptr = 2.f;
                             } else {
                                 rinv = sunInv;
-                                occ = false; sp = 0; cur = S.rootChild;
+                                occ = false; sp = 0; cur = S.rootChild; pend = RT_DONE;
+                                if (cur < 0) { pend = cur; cur = RT_DONE; }
                                 active = true;
                             }
                         }
@@ -400,7 +402,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                             } else {
                                 rinv = inv;
                                 lim = (kind == 0) ? (distToLight + distToLight * 1e-3f + S.cullAbs * 4.0f) : INF;
-                                occ = false; sp = 0; cur = S.rootChild;
+                                occ = false; sp = 0; cur = S.rootChild; pend = RT_DONE;
+                                if (cur < 0) { pend = cur; cur = RT_DONE; }
                                 active = true;
                             }
                         }
@@ -414,26 +417,37 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
         const bool canRefill = !wp.empty();
 
         for (;;) {
-            while (cur >= 0) {
-                const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-                float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                if (COUNT) nNodes++;
-                float te0, tx0, te1, tx1;
-                slab_pair_s(o, rinv, n0, n1, n2, te0, tx0, te1, tx1);
-                bool p0 = tx0 >= te0 && tx0 >= 0.0f && (SUN1 || !(te0 > lim));
-                bool p1 = tx1 >= te1 && tx1 >= 0.0f && (SUN1 || !(te1 > lim));
-                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                if (p0 && p1) {      // nearer box first: an occluder, if any, tends to be found sooner
-                    bool swap = te1 < te0;
-                    uint2 e; e.x = (uint32_t)(swap ? c0 : c1); e.y = 0u; stk.push(sp, e);
-                    cur = swap ? c1 : c0;
-                } else if (p0) cur = c0;
-                else if (p1) cur = c1;
-                else if (sp > 0) cur = (int)stk.pop(sp).x;
-                else cur = RT_DONE;
+            // node phase / triangle phase with parked leaves, as in k_extend_refill
+            for (;;) {
+                const bool hasNode = cur >= 0;
+                const int nNode = __popcll(__ballot(hasNode));
+                if (nNode == 0) break;
+                if (nNode < nodeMin) {
+                    const bool parked = __ballot(pend != RT_DONE) != 0ull;
+                    const int nFree = __popcll(__ballot(!active || (cur == RT_DONE && pend == RT_DONE)));
+                    if (parked || (canRefill && nFree >= refillIdle)) break;
+                }
+                if (hasNode) {
+                    const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+                    float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    if (COUNT) nNodes++;
+                    float te0, tx0, te1, tx1;
+                    slab_pair_s(o, rinv, n0, n1, n2, te0, tx0, te1, tx1);
+                    bool p0 = tx0 >= te0 && tx0 >= 0.0f && (SUN1 || !(te0 > lim));
+                    bool p1 = tx1 >= te1 && tx1 >= 0.0f && (SUN1 || !(te1 > lim));
+                    int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                    if (p0 && p1) {      // nearer box first: an occluder, if any, tends to be found sooner
+                        bool swap = te1 < te0;
+                        uint2 e; e.x = (uint32_t)(swap ? c0 : c1); e.y = 0u; stk.push(sp, e);
+                        cur = swap ? c1 : c0;
+                    } else if (p0) cur = c0;
+                    else if (p1) cur = c1;
+                    else popS();
+                    if (cur < 0 && cur != RT_DONE && pend == RT_DONE) { pend = cur; popS(); }
+                }
             }
-            if (cur != RT_DONE) {
-                int code = -cur - 1;
+            if (pend != RT_DONE) {
+                int code = -pend - 1;
                 int first = code >> 3, cnt = code & 7;
                 const float4* tp = reinterpret_cast<const float4*>(S.tris + first);
                 for (int k = 0; k < cnt; k++) {
@@ -444,11 +458,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                         else { v3 h = o + d * t; v3 dl = h - shadeLoc; if (sqrtf(dot3(dl, dl)) < distToLight) occ = true; }
                     }
                 }
-                if (occ) cur = RT_DONE;
-                else if (sp > 0) cur = (int)stk.pop(sp).x;
-                else cur = RT_DONE;
+                pend = RT_DONE;
+                if (occ) { cur = RT_DONE; sp = 0; }
+                else if (cur < 0 && cur != RT_DONE) { pend = cur; popS(); }
             }
-            if (active && cur == RT_DONE) {
+            if (active && cur == RT_DONE && pend == RT_DONE) {
                 *wptr = occ ? 0.f : 2.f;
                 active = false;
             }
