@@ -67,7 +67,7 @@ struct rt_ctx {
     hipEvent_t evResolve[kMaxSets] = {}, evInit = nullptr;
     int32_t passStreams = 4, autoPass = 1;
     // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill 0 = never, 1 = always, -1 = chosen per scene.
-    int32_t refill = -1, refillIdle = 8, refillNodeMin = 28, refillBlocksPerCU = 0;   // refillBlocksPerCU 0 = automatic (refill_blocks)
+    int32_t refill = -1, refillIdle = 16, refillNodeMin = 28, refillBlocksPerCU = 0;   // refillBlocksPerCU 0 = automatic (refill_blocks)
     // refill = -1: which traversal kernels are faster depends on the scene, and not the same way for closest-hit and
     // shadow rays (scene 7: closest hit +14 % with refill, one-sun shadow rays -5 %; scene 4: batch for both; the
     // 20 M-triangle field: refill for both), so the first four sizeable frames after a scene upload are rendered with
