@@ -8,6 +8,8 @@ A step = one complete frame (all samples, all bounces) of the hot path with the 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's samples are split into N
 contiguous ranges (scene + BVH replicated), every rank traces its range over the whole image and the HDR
 colour buffers are summed onto rank 0 with one RCCL reduce — the only collective (strong scaling).
+Before the warm-up every rank renders --prepare-frames frames (default 5): the first allocates the path buffers, the
+next four are the library's per-scene trial of its traversal kernels (scene preparation, reported in scene_load_s).
 Rank 0 prints ONE JSON line.  One ray = one lineCast of shader.comp (camera/bounce segment or shadow ray)
 actually traced by the kernels (device counters).
 """
@@ -41,7 +43,10 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=5)      # frame 1 allocates, frames 2 to 5 are the library's trial of its traversal kernels (rt_core.h, refill)
+    ap.add_argument("--warmup", type=int, default=2)
+    # scene preparation, before the warm-up: frame 1 allocates the path buffers, frames 2 to 5 are the library's trial of
+    # its traversal kernels for this scene (rt_core.h, refill); reported as scene_load_s.kernel_trial_s
+    ap.add_argument("--prepare-frames", type=int, default=5)
     # workload = a BASELINE.json config; c2 is the headline (the default), the others are reported for context
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     # development overrides (a run with any of these set is labelled in config and is not the headline)
@@ -169,6 +174,12 @@ def main():
             torch.cuda.synchronize()                 # the reduce runs on the process group's stream; the next frame clears `color`
         return cs.stats()
 
+    t_prep = time.perf_counter()
+    for _ in range(args.prepare_frames):
+        cs.dispatch_region(0, 0, W, H, r0, r1)
+    torch.cuda.synchronize()
+    load_t = dict(load_t)
+    load_t["kernel_trial_s"] = round(time.perf_counter() - t_prep, 3)
     cs.setInt("timeKernels", 0 if args.no_kernel_timing else 1)     # HIP events around every kernel, on the launch stream, live in the timed region
     for _ in range(args.warmup):
         step()
