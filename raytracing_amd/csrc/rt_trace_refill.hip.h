@@ -89,6 +89,11 @@ __device__ __forceinline__ void slab_pair_s(v3 o, v3 inv, float4 n0, float4 n1, 
 // idle lane a few LDS reads.  (Setting rays up inside the refill, with only the idle lanes active, made every refill
 // as expensive as a full wave's set-up.)
 #define RT_POOL_WORDS 10     // o.xyz, d.xyz, 1/d.xyz, queue entry
+// Below `nodeMin` lanes with a node to visit, the node phase of the refill kernels goes on until RT_TRI_MIN lanes have a
+// leaf parked (so that the triangle phase runs with a fuller wave too) or fewer than RT_NODE_LOW lanes have a node
+// (measured 16/12, 32/8, 48/4: 32/8 best on C2..C5).
+#define RT_TRI_MIN 32
+#define RT_NODE_LOW 8
 template <bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
                                                          const float4* __restrict__ rays, const uint32_t* __restrict__ count,
@@ -214,9 +219,9 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
                 const int nNode = __popcll(__ballot(hasNode));
                 if (nNode == 0) break;
                 if (nNode < nodeMin) {
-                    const bool parked = __ballot(pend != RT_DONE) != 0ull;
+                    const int nParked = __popcll(__ballot(pend != RT_DONE));
                     const int nFree = __popcll(__ballot(!active || (cur == RT_DONE && pend == RT_DONE)));
-                    if (parked || (canRefill && nFree >= refillIdle)) break;
+                    if (nParked >= RT_TRI_MIN || (nParked > 0 && nNode < RT_NODE_LOW) || (canRefill && nFree >= refillIdle)) break;
                 }
                 if (hasNode) {
                     const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
@@ -423,9 +428,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                 const int nNode = __popcll(__ballot(hasNode));
                 if (nNode == 0) break;
                 if (nNode < nodeMin) {
-                    const bool parked = __ballot(pend != RT_DONE) != 0ull;
+                    const int nParked = __popcll(__ballot(pend != RT_DONE));
                     const int nFree = __popcll(__ballot(!active || (cur == RT_DONE && pend == RT_DONE)));
-                    if (parked || (canRefill && nFree >= refillIdle)) break;
+                    if (nParked >= RT_TRI_MIN || (nParked > 0 && nNode < RT_NODE_LOW) || (canRefill && nFree >= refillIdle)) break;
                 }
                 if (hasNode) {
                     const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
