@@ -31,7 +31,7 @@ def main():
     cs.setInt("samplesPerPixel", args.spp)
     cs.setInt("maxBounces", args.bounces)
     S.set_camera(cs, S.DEFAULT_CAMERA[0], S.DEFAULT_CAMERA[1], W, H, 45.0)
-    for _ in range(3):                                   # allocation + the library's kernel trial
+    for _ in range(5):                                   # allocation + the library's four-frame kernel trial
         cs.dispatch_region(0, 0, W, H, 0, args.spp)
     base = None
     for n in (1, 2, 4, 8):
