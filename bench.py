@@ -128,6 +128,7 @@ def main():
     from raytracing_amd import ComputeShader
     from raytracing_amd import scene as S
     from raytracing_amd.distributed import image_tensor, sample_range
+    from raytracing_amd import render_path
 
     cs = ComputeShader(device=dev, rank=rank, world_size=world)
     if args.scene == 0:
@@ -165,8 +166,8 @@ def main():
 
     def step():
         if args.workload == "c5":                    # the camera path of the offline render: frame f of the orbit
-            frame_no[0] += 1
-            pos, ori = S.orbit_camera(frame_no[0])
+            frame_no[0] += 1                         # exported frame f >= 1 is rendered with UpdateCamera(currentFrame = f - 1)
+            pos, ori = render_path.frame_camera(frame_no[0])
             S.set_camera(cs, pos, ori, W, H, 45.0)
         cs.dispatch_region(0, 0, W, H, r0, r1)       # returns with the images complete
         if world > 1:

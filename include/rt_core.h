@@ -103,7 +103,8 @@ rt_status rt_render_frame(rt_ctx* ctx);
 /* Partition form used by the multi-GPU driver (no reference counterpart; the reference is single-GPU):
  * traces pixels [x,x+w) x [y,y+h) and samples [spp_begin, spp_end) of samplesPerPixel.  Pixels outside the
  * region are zero in all four images; the AOV images (albedo, normal, depth) are written when spp_begin == 0 and
- * are all-zero otherwise, so partial renders merge with one element-wise sum. */
+ * are all-zero otherwise, and the colour image's alpha is 1 when spp_begin == 0 and 0 otherwise, so partial renders
+ * merge with one element-wise sum into exactly the single-call frame's layout (alpha 1 in all four images). */
 rt_status rt_render_region(rt_ctx* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
                            uint32_t spp_begin, uint32_t spp_end);
 

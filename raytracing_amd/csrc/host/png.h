@@ -27,13 +27,18 @@ inline ImageRGBA8 decode_png(const std::vector<uint8_t>& f) {
         std::string type((const char*)&f[o + 4], 4);
         if (o + 12 + len > f.size()) throw std::runtime_error("png: truncated chunk");
         const uint8_t* d = &f[o + 8];
-        if (type == "IHDR") { W = be32(o + 8); H = be32(o + 12); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+        if (type == "IHDR") {
+            if (len != 13) throw std::runtime_error("png: IHDR chunk is not 13 bytes");
+            W = be32(o + 8); H = be32(o + 12); depth = d[8]; ctype = d[9]; interlace = d[12];
+        }
         else if (type == "IDAT") idat.insert(idat.end(), d, d + len);
         else if (type == "PLTE") plte.assign(d, d + len);
         else if (type == "tRNS") trns.assign(d, d + len);
         else if (type == "IEND") break;
         o += 12 + len;
     }
+    // a header that is missing, empty or absurd (the pixel buffers below are sized from it) is refused before anything is allocated
+    if (W == 0 || H == 0 || (uint64_t)W * H > (1ull << 28)) throw std::runtime_error("png: missing IHDR or image size out of range (1 .. 2^28 pixels)");
     if (depth != 8 || interlace != 0) throw std::runtime_error("png: only 8-bit non-interlaced images are supported");
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch) throw std::runtime_error("png: bad colour type");

@@ -221,6 +221,15 @@ uint32_t refill_blocks(rt_ctx* c, uint32_t nItems, int nSets) {
     uint32_t most = (uint32_t)c->numCUs * (uint32_t)perCU;
     return std::max(1u, itemBlocks < most ? itemBlocks : most);
 }
+// Threads that may hold a traversal stack at one time = the largest grid any traversal kernel is launched with
+// (batch kernels: trace_blocks; refill kernels: refill_blocks with 4, 6 or refillBlocksPerCU workgroups per CU).  The
+// overflow area and its stride are sized from this, so that entry k of thread g never aliases another thread's.
+uint32_t stack_blocks(rt_ctx* c, uint32_t nslots) {
+    uint32_t slotBlocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
+    const uint32_t perCU = (uint32_t)std::max(std::max((int)c->blocksPerCU, 6), (int)c->refillBlocksPerCU);
+    uint32_t most = (uint32_t)c->numCUs * perCU;
+    return std::max(1u, slotBlocks < most ? slotBlocks : most);
+}
 uint32_t overflow_depth(rt_ctx* c) {
     // ordered traversal keeps at most one pending sibling per level: depth <= tree depth
     int need = (int)c->cs.maxDepth + 1 - RT_LDS_STACK;
@@ -238,7 +247,7 @@ rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
     rt_status s;
     size_t n = nslots;
     rt_ctx::PathSet& ps = c->set[which];
-    if ((s = ensure(c, ps.overflow, (size_t)overflow_depth(c) * trace_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
+    if ((s = ensure(c, ps.overflow, (size_t)overflow_depth(c) * stack_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
     for (int k = 0; k < 2; k++) {
         if ((s = ensure(c, ps.ray[k], n * 32))) return s;
         if ((s = ensure(c, ps.rayS[k], n * 16))) return s;
@@ -262,7 +271,7 @@ PathBuffers make_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
     P.contrib = (float4*)ps.contrib.p; P.depth = (uint32_t*)ps.depth.p; P.accum = (float4*)c->accum.p;
     P.counters = (uint32_t*)ps.counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots;
-    P.overflow = (uint2*)ps.overflow.p; P.overflowStride = trace_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
+    P.overflow = (uint2*)ps.overflow.p; P.overflowStride = stack_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
 }
 
@@ -280,7 +289,8 @@ void launch_shadow(bool exact, bool count, dim3 g, hipStream_t st, Args... a) {
 rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint32_t r0, uint32_t r1) {
     if (!c) return RT_ERR_INVALID;
     if (c->width == 0 || c->height == 0) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
-    if (w == 0 || h == 0 || x + w > c->width || y + h > c->height) return fail(c, RT_ERR_INVALID, "region outside the image");
+    if (w == 0 || h == 0 || x >= c->width || w > c->width - x || y >= c->height || h > c->height - y)      // (no 32-bit wrap in x + w)
+        return fail(c, RT_ERR_INVALID, "region outside the image");
     if (c->samplesPerPixel < 1 || c->maxBounces < 0) return fail(c, RT_ERR_INVALID, "samplesPerPixel must be >= 1 and maxBounces >= 0");
     if (r0 > r1 || r1 > (uint32_t)c->samplesPerPixel) return fail(c, RT_ERR_INVALID, "sample range outside [0, samplesPerPixel]");
     rt_status s = sync_scene(c);
@@ -481,7 +491,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         if (nSets > 1) HIPCHK(c, hipEventRecord(c->evResolve[ks], st));
         passNo++;
     }
-    k_finalize<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, (float4*)c->img[0].p);     // on the last pass's stream, after its replay
+    k_finalize<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, (float4*)c->img[0].p, aov ? 1.f : 0.f);     // on the last pass's stream, after its replay
     HIPCHK(c, hipGetLastError());
     for (int k = 0; k < nSets; k++) HIPCHK(c, hipStreamSynchronize(streams[k]));
     if (timeKernels) for (auto& e : c->evRing) evDrain(e);

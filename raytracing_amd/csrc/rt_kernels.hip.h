@@ -1017,14 +1017,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_init_frame(FrameParams F, PathBuff
 }
 
 // shader.comp:533 — un-swizzle the tile-ordered accumulators into the row-major colour image.
-__global__ __launch_bounds__(RT_BLOCK) void k_finalize(FrameParams F, PathBuffers P, float4* imgColor) {
+// alpha: 1 (the shader's vec4(color, 1)) for the call whose sample range holds sample 0, 0 for the other sample ranges of
+// a split frame, so that the element-wise sum that merges partial renders leaves alpha at 1 like the AOV images'.
+__global__ __launch_bounds__(RT_BLOCK) void k_finalize(FrameParams F, PathBuffers P, float4* imgColor, float alpha) {
     uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (slot >= P.slotsPerSample) return;
     int px, py;
     slot_to_pixel(F, slot, &px, &py);
     if (px < F.rx + F.rw && py < F.ry + F.rh) {
         float4 c = P.accum[slot];
-        imgColor[(size_t)py * F.width + px] = make_float4(c.x, c.y, c.z, 1.f);
+        imgColor[(size_t)py * F.width + px] = make_float4(c.x, c.y, c.z, alpha);
     }
 }
 

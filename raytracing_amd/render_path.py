@@ -6,8 +6,9 @@ Renderer.cpp:19-193) — a 120-frame orbit of the scene — on N MI355X, headles
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m raytracing_amd.render_path ...
 
 Frame f is rendered with the camera the reference would have at that frame: frame 0 with the camera the user left
-(the default camera here, main.cpp:239), frame f >= 1 with UpdateCamera's orbit for currentFrame = f
-(Renderer.cpp:151,187-193: the camera moves after a frame is encoded).  Two ways to use N GPUs:
+(the default camera here, main.cpp:239), frame f >= 1 with UpdateCamera's orbit for currentFrame = f - 1: NextFrame
+encodes frame f - 1, calls UpdateCamera and only then increments currentFrame (Renderer.cpp:151,164,187-193), and
+main.cpp sets the uniforms and dispatches before it calls NextFrame (main.cpp:111,138,198).  Two ways to use N GPUs:
   --split samples (default)  every frame is split into N sample ranges (x row bands with --band-ranks) and the HDR
                              colour buffers are summed onto rank 0 with one RCCL reduce (the only collective);
   --split frames             rank r renders frames r, r + N, ... on its own: no collective at all.
@@ -23,8 +24,9 @@ import time
 
 
 def frame_camera(f):
+    """Camera of exported frame f: the user's camera for frame 0, UpdateCamera with currentFrame = f - 1 after it."""
     from . import scene as S
-    return S.DEFAULT_CAMERA if f == 0 else S.orbit_camera(f)
+    return S.DEFAULT_CAMERA if f == 0 else S.orbit_camera(f - 1)
 
 
 def write_ppm(path, rgba8):

@@ -81,6 +81,8 @@ def test_region_is_bit_identical_and_sample_ranges_sum(oracle_lib, scene4):
     assert np.allclose(a[0][..., :3] + c[0][..., :3], full[0][..., :3], rtol=1e-5, atol=1e-6)
     for k in (1, 2, 3):
         assert same_floats(a[k], full[k]).all() and (c[k] == 0).all()
+    # alpha: 1 from the range holding r = 0, 0 from the others, so the merged frame has the shader's vec4(rgb, 1)
+    assert (a[0][..., 3] == 1).all() and (c[0][..., 3] == 0).all() and (full[0][..., 3] == 1).all()
     # empty sample range: clears, traces nothing
     e = _render(cs, spp_range=(2, 2))
     assert (e[0][..., :3] == 0).all() and cs.stats()["rays_primary"] == 0
@@ -138,6 +140,10 @@ def test_errors_are_reported_not_crashes(scene4):
     assert e.value.status == 5
     with pytest.raises(RtError):
         cs.dispatch_region(0, 0, 17, 16, 0, 1)      # region outside the image
+    for bad_region in ((0xFFFFFFFF, 0, 2, 1), (0, 0xFFFFFFFF, 1, 2), (15, 0, 0xFFFFFFF2, 1), (16, 0, 1, 1), (0, 0, 0, 1)):
+        with pytest.raises(RtError) as e:           # x + w wraps in 32 bits: still refused
+            cs.dispatch_region(*bad_region, 0, 1)
+        assert e.value.status == 2
     cs.setInt("projection", 1)                      # unknown uniform names are ignored like GL location -1
     cs.setMat4("invView", np.eye(4))
     cs.Delete()
@@ -229,7 +235,7 @@ def test_frame_rgba8_is_the_reference_conversion(scene4):
 
 def test_camera_path_driver_writes_reference_frames(oracle_lib, models_root, tmp_path):
     """Config 5's driver (raytracing_amd/render_path.py = Renderer::Start/NextFrame/UpdateCamera): frame 0 with the
-    default camera, frame f >= 1 with the orbit camera of frame f, 8-bit PPM frames as Renderer.cpp:103-124 converts them."""
+    default camera, frame f >= 1 with the orbit camera of UpdateCamera(currentFrame = f - 1), 8-bit PPM frames as Renderer.cpp:103-124 converts them."""
     from raytracing_amd import render_path
     W, H, spp, b = 64, 36, 2, 4
     render_path.main(["--scene", "4", "--models", models_root, "--width", str(W), "--height", str(H), "--spp", str(spp),
@@ -291,6 +297,32 @@ def test_full_size_frame_is_reproducible_and_stream_independent(oracle_lib, scen
         assert np.array_equal(bits(cs.get_image(0)), bits(first)), knobs
         for k in knobs:
             cs.setInt(k, {"passStreams": 0, "samplesPerPass": 64, "autoPass": 1, "refill": -1, "blocksPerCU": 64}[k])
+    cs.Delete()
+
+
+def test_small_batch_grid_with_refill_kernels_keeps_stacks_apart(models_root):
+    """blocksPerCU = 1 shrinks the batch kernels' grid below the refill kernels' (4 to 6 workgroups per CU): the stack
+    overflow area is sized and strided for the larger of the two, so deep stacks (scene 7: 21 levels, 8 in LDS) of
+    different threads never alias.  Frame of 0.9 M slots per pass, far more than either grid."""
+    from raytracing_amd import ComputeShader
+    from raytracing_amd import scene as S
+    W, H, spp = 640, 360, 4
+    cs = ComputeShader()
+    S.Scene.LoadScene(cs, 7, models_root)
+    cs.resize(W, H)
+    cs.setInt("samplesPerPixel", spp)
+    cs.setInt("maxBounces", 8)
+    S.set_camera(cs, S.DEFAULT_CAMERA[0], S.DEFAULT_CAMERA[1], W, H, 45.0)
+    cs.setInt("refill", 0)
+    cs.dispatch()
+    first = cs.get_image(0).copy()
+    for knobs in ({"refill": 1, "blocksPerCU": 1}, {"refill": 1, "blocksPerCU": 2, "refillBlocksPerCU": 9}, {"refill": 1, "passStreams": 1, "blocksPerCU": 1}):
+        for k, v in knobs.items():
+            cs.setInt(k, v)
+        cs.dispatch()
+        assert np.array_equal(bits(cs.get_image(0)), bits(first)), knobs
+        for k in knobs:
+            cs.setInt(k, {"passStreams": 0, "refill": 0, "blocksPerCU": 64, "refillBlocksPerCU": 0}[k])
     cs.Delete()
 
 

@@ -64,10 +64,12 @@ def test_two_ranks_on_one_gpu_merge_to_the_single_process_frame(tmp_path, band_r
     full = [cs.get_image(k) for k in range(4)]
     cs.Delete()
 
-    color, want = got["img0"][..., :3], full[0][..., :3]
+    # all four channels: alpha is 1 in the merged frame too (only the rank whose range holds sample 0 stores it)
+    color, want = got["img0"], full[0]
+    assert (color[..., 3] == 1.0).all()
     if band_ranks == 2:
         assert np.array_equal(color.view(np.uint32), want.view(np.uint32))
     else:
         assert np.allclose(color, want, rtol=1e-5, atol=1e-6)
     for k in (1, 2, 3):      # AOVs come from sample 0 alone: exact under either split
-        assert np.array_equal(got["img%d" % k][..., :3].view(np.uint32), full[k][..., :3].view(np.uint32)), k
+        assert np.array_equal(got["img%d" % k].view(np.uint32), full[k].view(np.uint32)), k

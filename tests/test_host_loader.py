@@ -105,6 +105,24 @@ def test_camera_helpers_match_oracle():
         assert np.allclose(pos, wp, rtol=0, atol=2e-6) and np.allclose(ori, wo, rtol=0, atol=2e-7)
 
 
+def test_exported_frame_uses_the_camera_of_the_previous_update():
+    """Renderer::NextFrame encodes frame f, calls UpdateCamera and only then increments currentFrame (Renderer.cpp:151,164),
+    and main.cpp dispatches before NextFrame (main.cpp:138,198): exported frame 0 shows the user's camera, frame 1
+    UpdateCamera with currentFrame = 0 (x = -PI/6), frame f >= 1 the orbit step f - 1; orbit step 119 is never rendered."""
+    import math
+    from raytracing_amd import render_path
+    from raytracing_amd import scene as S
+    assert render_path.frame_camera(0) == S.DEFAULT_CAMERA
+    pos, ori = render_path.frame_camera(1)
+    x = np.float32(0.0) / np.float32(120.0) - np.float32(3.14159265359) / np.float32(6.0)
+    assert np.allclose(pos, (math.sin(x) * 15.0, 3.5, math.cos(x) * 15.0), rtol=0, atol=2e-6)
+    assert render_path.frame_camera(1) == S.orbit_camera(0)
+    for f in (2, 60, 119):
+        assert render_path.frame_camera(f) == S.orbit_camera(f - 1)
+        wp, wo = G.orbit_camera(f - 1)
+        assert np.allclose(render_path.frame_camera(f)[0], wp, rtol=0, atol=2e-6)
+
+
 def test_node_transforms_children_and_the_q12_walk(oracle_lib, models_root, tmp_path):
     """A GLTF with what none of the bundled files has: TRS and `matrix` node transforms, `children`, several nodes.
     Model::traverseNode (model.cpp:74-147) composes matrix * node.matrix * T * R * S down the hierarchy and, after a

@@ -88,6 +88,21 @@ int main(int argc, char** argv) {
         px = nullptr;
         (void)rth_decode_png(tmp, &px, &w, &h);                                       // either outcome, but no memory error
         rth_free(px);
+        // a short IHDR chunk at the end of the file (its fields used to be read past the buffer) and a header whose
+        // width x height would size a 2^62-byte buffer: both are refused
+        {
+            const uint8_t shortHdr[] = {137, 80, 78, 71, 13, 10, 26, 10, 0, 0, 0, 4, 'I', 'H', 'D', 'R', 0, 0, 0, 1, 0, 0, 0, 0};
+            f = std::fopen(tmp, "wb"); std::fwrite(shortHdr, 1, sizeof shortHdr, f); std::fclose(f);
+            px = nullptr;
+            EXPECT(rth_decode_png(tmp, &px, &w, &h) != RT_OK);
+            rth_free(px);
+            std::vector<uint8_t> huge = bytes;
+            if (huge.size() >= 24) { for (int k = 16; k < 24; k++) huge[k] = 0x7f; }    // W = H = 0x7f7f7f7f
+            f = std::fopen(tmp, "wb"); std::fwrite(huge.data(), 1, huge.size(), f); std::fclose(f);
+            px = nullptr;
+            EXPECT(rth_decode_png(tmp, &px, &w, &h) != RT_OK);
+            rth_free(px);
+        }
         std::remove(tmp);
     }
     {   // the core's compaction of uploaded buffers: a good scene, then inconsistent ones (errors, never memory errors)
