@@ -160,6 +160,19 @@ rt_status rt_read_primary_hits(rt_ctx* ctx, int32_t* tri_ids, float* hit_locs);
 rt_status rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint64_t n,
                         int32_t* tri_ids, float* hit_locs);
 
+/* rt_trace_rays for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  No counterpart in the reference.  Same arguments, same kernels and bit-identical results, but the
+ * ray queue, hit records, queue counter, traversal-stack overflow and the staged inputs / outputs live in a file-scope
+ * device array of the library (about 8.4 MB, held by every GPU the library runs on until the process ends) instead of
+ * hipMalloc'ed buffers, and the call makes no hipMalloc / hipFree / allocating library call.  Limits: n <=
+ * RT_NOALLOC_MAX_RAYS per call (more: RT_ERR_INVALID); the scene must already be resident, i.e. an rt_render_* or
+ * rt_trace_rays call has run since the last upload of slots 0..4 (otherwise RT_ERR_NOT_READY: deriving the compact scene
+ * allocates); hit_locs is required.  All contexts on one GPU share that GPU's array and it keeps the last call's
+ * contents (the call clears what must start at zero): calls that overlap on one GPU race, so serialise them per GPU. */
+#define RT_NOALLOC_MAX_RAYS 16384
+rt_status rt_trace_rays_noalloc(rt_ctx* ctx, const float* origins, const float* dirs, uint64_t n,
+                                int32_t* tri_ids, float* hit_locs);
+
 #ifdef __cplusplus
 }
 #endif

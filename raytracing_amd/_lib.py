@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("RT_CORE_LIB") or os.path.join(_HERE, "librt_core.so")
 EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_buffer", "rt_set_int", "rt_set_float",
            "rt_set_vec2", "rt_set_vec3", "rt_set_vec4", "rt_set_mat4", "rt_resize", "rt_create_texture",
            "rt_render_frame", "rt_render_region", "rt_read_image", "rt_write_image", "rt_read_image_rgb", "rt_write_image_rgb", "rt_read_frame_rgba8", "rt_image_device_ptr",
-           "rt_get_stats", "rt_read_primary_hits", "rt_trace_rays"]
+           "rt_get_stats", "rt_read_primary_hits", "rt_trace_rays", "rt_trace_rays_noalloc"]
 
 
 class RtConfig(C.Structure):
@@ -29,6 +29,8 @@ class RtStats(C.Structure):
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
+
+NOALLOC_MAX_RAYS = 16384      # RT_NOALLOC_MAX_RAYS of include/rt_core.h
 
 _lib = None
 
@@ -67,6 +69,7 @@ def load():
         "rt_get_stats": (i32, [vp, C.POINTER(RtStats)]),
         "rt_read_primary_hits": (i32, [vp, vp, vp]),
         "rt_trace_rays": (i32, [vp, vp, vp, u64, vp, vp]),
+        "rt_trace_rays_noalloc": (i32, [vp, vp, vp, u64, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -145,6 +145,18 @@ class ComputeShader:
                                         tri.ctypes.data_as(C.c_void_p), hit.ctypes.data_as(C.c_void_p)))
         return tri, hit
 
+    def trace_rays_noalloc(self, origins, dirs):
+        """rt_trace_rays_noalloc: the same query out of the library's file-scope scratch array, no allocation on the GPU;
+        at most _lib.NOALLOC_MAX_RAYS rays, scene already resident."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        tri = np.empty(len(o), np.int32)
+        hit = np.empty((len(o), 3), np.float32)
+        self._chk(self._L.rt_trace_rays_noalloc(self._h, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), len(o),
+                                                tri.ctypes.data_as(C.c_void_p), hit.ctypes.data_as(C.c_void_p)))
+        return tri, hit
+
 
 class SSBO:
     """SSBO::Bind(data, size, slot) (SSBO.cpp:5-17) — GL's implicit context is the explicit first argument."""

@@ -24,6 +24,21 @@ struct DevBuf {
 
 struct Texture { DevBuf data; uint32_t w = 0, h = 0; };
 
+// ---- rt_trace_rays_noalloc: device memory that is part of the library image, not of the heap -----------------------
+// Everything rt_trace_rays keeps in hipMalloc'ed buffers (ray queue, hit records, queue counter, traversal-stack
+// overflow, staged inputs and outputs) lives in this file-scope array for the allocation-free variant.  Each GPU the
+// library runs on holds its own copy until the process ends.  Layout for n rays (offsets in bytes, all 256-aligned):
+//   [0, 256)  queue counter + DeviceStats | rays 32 n | hits 8 n | origins 12 n | dirs 12 n | tri ids 4 n | hit locs 12 n |
+//   stack overflow 8 x RT_SPILL_STACK x n (the deepest tree the shader's 64-entry stack can hold)
+constexpr uint64_t kNoAllocMaxRays = RT_NOALLOC_MAX_RAYS;
+constexpr uint64_t kScratchHeader = 256;
+constexpr uint64_t kScratchBytes = kScratchHeader + kNoAllocMaxRays * (32 + 8 + 12 + 12 + 4 + 12 + 8ull * RT_SPILL_STACK) + 7 * 256;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+// `scratch` is a host-side stand-in in host code, not a device address: the address of each device's copy is looked up
+// once per device (rt_create, with that device current) and only these pointers are ever handed to kernels and copies.
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratchPtr[kMaxDevices] = {};
+
 }  // namespace
 
 struct rt_ctx {
@@ -528,6 +543,22 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     return RT_OK;
 }
 
+// rt_trace_rays_noalloc: what rt_trace_rays computes on the host from the hit records, on the device, so that the results
+// go straight from `scratch` into the caller's arrays: reference triangle id and hitLoc = orig + dir * t
+// (shader.comp:122; -ffp-contract=off, the same two roundings as the host loop of rt_trace_rays).
+__global__ void k_hits_out(const float2* __restrict__ hit, const float* __restrict__ origins, const float* __restrict__ dirs,
+                           uint32_t n, int32_t* __restrict__ triOut, float* __restrict__ locOut) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 h = hit[i];
+    const int32_t id = __float_as_int(h.y);
+    triOut[i] = id;
+    for (int k = 0; k < 3; k++) {
+        const float prod = dirs[3 * i + k] * h.x;
+        locOut[3 * i + k] = id >= 0 ? origins[3 * i + k] + prod : 0.f;
+    }
+}
+
 // RGBA32F image <-> tightly packed RGB (OIDN's Float3 layout; main.cpp:157-170 rgbaTOrgb and 176-183 on the way back)
 __global__ void k_pack_rgb(const float4* __restrict__ img, float* __restrict__ rgb, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -570,6 +601,13 @@ rt_status rt_create(rt_ctx** out, const rt_config* cfg) {
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available (librt_core has no CPU fallback)");
     if (dev < 0 || dev >= ndev) return fail(nullptr, RT_ERR_NO_DEVICE, "device ordinal out of range");
     if (hipSetDevice(dev) != hipSuccess) return fail(nullptr, RT_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (dev < kMaxDevices && !g_scratchPtr[dev]) {
+        // this device's copy of the file-scope scratch array (rt_trace_rays_noalloc), looked up with the device current
+        void* sp = nullptr;
+        hipError_t se = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+        if (se != hipSuccess || !sp) return fail(nullptr, RT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se));
+        g_scratchPtr[dev] = (unsigned char*)sp;
+    }
     rt_ctx* c = new rt_ctx();
     c->device = dev;
     hipDeviceProp_t prop;
@@ -834,6 +872,69 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
             }
         }
     }
+    std::memset(&c->stats, 0, sizeof c->stats);
+    c->stats.rays_primary = hs.rays_primary + hs.rays_bounce; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
+    return RT_OK;
+}
+
+rt_status rt_trace_rays_noalloc(rt_ctx* c, const float* origins, const float* dirs, uint64_t n, int32_t* tri, float* hits) {
+    if (!c) return RT_ERR_INVALID;
+    if (!origins || !dirs || !tri || !hits) return fail(c, RT_ERR_INVALID, "NULL argument");
+    if (n == 0) return RT_OK;
+    if (n > kNoAllocMaxRays) return fail(c, RT_ERR_INVALID, "rt_trace_rays_noalloc takes at most RT_NOALLOC_MAX_RAYS (" + std::to_string(kNoAllocMaxRays) + ") rays per call");
+    // Deriving and uploading the compact scene allocates: it must have happened already (any rt_render_* or rt_trace_rays
+    // call after the last upload of slots 0..4 does it).
+    for (int s : {RT_SLOT_VERTICES, RT_SLOT_MESH_MATRICES, RT_SLOT_MATERIALS, RT_SLOT_BVH_NODES, RT_SLOT_TRIANGLES})
+        if (!c->slotSet[s]) return fail(c, RT_ERR_NOT_READY, "slot " + std::to_string(s) + " has not been uploaded");
+    if (c->sceneDirty || !c->dNodes.p || !c->dTris.p)
+        return fail(c, RT_ERR_NOT_READY, "the scene is not resident yet: call rt_render_frame / rt_render_region / rt_trace_rays once after uploading it");
+    if (c->device >= kMaxDevices || !g_scratchPtr[c->device]) return fail(c, RT_ERR_HIP, "no scratch address for this device");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned char* base = g_scratchPtr[c->device];      // never the array's name: that is not a device address here
+    const uint32_t nn = (uint32_t)n;
+    const uint32_t nslots = (nn + 63u) / 64u * 64u;
+    const uint32_t blocks = (nslots + RT_BLOCK - 1) / RT_BLOCK;
+    auto up = [](uint64_t v) { return (v + 255) / 256 * 256; };
+    uint64_t off = kScratchHeader;
+    float4* dRay = (float4*)(base + off);   off = up(off + 32ull * nslots);
+    float2* dHit = (float2*)(base + off);   off = up(off + 8ull * nslots);
+    float* dO = (float*)(base + off);       off = up(off + 12ull * nn);
+    float* dD = (float*)(base + off);       off = up(off + 12ull * nn);
+    int32_t* dTri = (int32_t*)(base + off); off = up(off + 4ull * nn);
+    float* dLoc = (float*)(base + off);     off = up(off + 12ull * nn);
+    uint2* dOv = (uint2*)(base + off);
+    const uint32_t ovDepth = overflow_depth(c), ovStride = blocks * RT_BLOCK;
+    off += 8ull * ovDepth * ovStride;
+    if (off > kScratchBytes) return fail(c, RT_ERR_INVALID, "internal error: scratch layout exceeds the array");
+    uint32_t* dCount = (uint32_t*)base;
+    DeviceStats* dst = (DeviceStats*)(base + 64);
+    static_assert(64 + sizeof(DeviceStats) <= kScratchHeader, "scratch header");
+
+    PathBuffers P;
+    std::memset(&P, 0, sizeof P);
+    P.ray[0] = dRay; P.hit = dHit; P.counters = dCount;
+    P.nslots = nslots; P.slotsPerSample = nslots; P.lightSlots = 1;
+    P.overflow = dOv; P.overflowStride = ovStride; P.overflowDepth = ovDepth;
+    const bool exact = use_exact(c);
+    const bool count = c->countVisits != 0;
+    SceneView S = make_view(c, exact);
+    hipStream_t st = c->stream;
+    // the array keeps the previous call's contents: the header (queue counter, statistics) starts at zero; everything else
+    // a call reads it has written first (rays, hits and results for i < n; stack entries are pushed before they are popped)
+    HIPCHK(c, hipMemsetAsync(base, 0, kScratchHeader, st));
+    HIPCHK(c, hipMemcpyAsync(dO, origins, 12ull * nn, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dD, dirs, 12ull * nn, hipMemcpyHostToDevice, st));
+    k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, dO, dD, nn, dCount);
+    FrameParams F0;
+    std::memset(&F0, 0, sizeof F0);
+    launch_extend<false>(exact, count, dim3(blocks), st, S, F0, P, (const float4*)dRay, (const uint32_t*)dCount, 0, 0u, dst);
+    k_hits_out<<<(nn + 255u) / 256u, 256, 0, st>>>(dHit, dO, dD, nn, dTri, dLoc);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(tri, dTri, 4ull * nn, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hits, dLoc, 12ull * nn, hipMemcpyDeviceToHost, st));
+    DeviceStats hs;
+    HIPCHK(c, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     std::memset(&c->stats, 0, sizeof c->stats);
     c->stats.rays_primary = hs.rays_primary + hs.rays_bounce; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
     return RT_OK;
