@@ -82,6 +82,15 @@ class Scene:
         return C.string_at(p.value, n.value) if n.value else b""
 
     @staticmethod
+    def buffer_view(slot):
+        """The same without a copy: a uint8 numpy view of the loader's own array (valid until the next load)."""
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(_L().rth_scene_buffer(slot, C.byref(p), C.byref(n)))
+        if not n.value:
+            return np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,))
+
+    @staticmethod
     def timings():
         t = (C.c_double * 3)()
         _chk(_L().rth_load_timings(t))
