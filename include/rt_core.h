@@ -79,7 +79,8 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * sum is still replayed in sample order, so results do not depend on it), refill (-1 automatic / 0 / 1: persistent
  * traversal waves that hand finished lanes new rays; automatic = the first four sizeable frames after a scene upload
  * are rendered with the four combinations (refill or not, for closest-hit and for shadow rays) and the fastest is kept;
- * until then BVHs far larger than the L2s use them and others do not), refillIdle, refillNodeMin,
+ * until then BVHs far larger than the L2s use them and others do not), kernelChoice (-1 / 0..3: that combination whatever
+ * was measured, reported back in rt_stats.kernel_choice; a multi-GPU job gives every rank rank 0's), refillIdle, refillNodeMin,
  * refillBlocksPerCU. */
 rt_status rt_set_int(rt_ctx* ctx, const char* name, int32_t v);
 rt_status rt_set_float(rt_ctx* ctx, const char* name, float v);
@@ -149,6 +150,11 @@ typedef struct rt_stats {
     uint64_t bounce_tri_tests;
     uint64_t wave_node_steps;  /* wave-level executions of the node step / triangle step by those kernels:   */
     uint64_t wave_tri_steps;   /* lane utilisation of a step = visits / (64 x executions)                     */
+    double   ms_extend_primary;      /* the part of ms_extend / launches_extend spent on camera rays (bounce 0)       */
+    uint64_t launches_extend_primary;
+    int32_t  kernel_choice;    /* traversal kernels this call ran: bit 0 = refill kernel for closest-hit rays of bounces >= 1,
+                                  bit 1 = for shadow rays; -2 = reference-order walk (traversalMode 1 or forced) */
+    int32_t  kernel_choice_settled;  /* 1: fixed by a knob or by the finished per-scene trial; 0: a trial frame or the default */
 } rt_stats;
 rt_status rt_get_stats(rt_ctx* ctx, rt_stats* out);
 

@@ -91,6 +91,8 @@ struct rt_ctx {
     int tuneState = 0;          // 0..3: the next sizeable frame samples combination kTuneTrial[tuneState]; 4: decided
     double tuneRate[4] = {0.0, 0.0, 0.0, 0.0};
     int tuneChoice = 0;         // bit 0: refill kernel for closest-hit rays, bit 1: for shadow rays
+    int32_t kernelChoice = -1;  // >= 0: this combination (bit 0 / bit 1 as tuneChoice) whatever was measured: every rank of a
+                                // multi-GPU job is given rank 0's choice, so that shards cost the same everywhere
     int32_t sunKernel = 1;      // 0: the general k_shadow also for one-sun scenes (A/B knob)
     bool anyTextured = true, anyTransmissive = true;   // which k_shade variant the scene needs (set with the materials)
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
@@ -406,9 +408,9 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     // Which traversal kernels: bit 0 = refill kernel for closest-hit rays, bit 1 = for shadow rays.
     static const int kTuneTrial[4] = {0, 3, 1, 2};
     const int comboDefault = bigScene ? 3 : 0;      // until measured: refill where traversal is bound by miss latency
-    const bool trial = !exact && !count && c->refill < 0 && c->tuneState < 4 &&
+    const bool trial = !exact && !count && c->refill < 0 && c->kernelChoice < 0 && c->tuneState < 4 &&
                        (double)w * (double)h * (double)(r1 - r0) >= 2.5e7;      // a frame large enough to be a measurement
-    const int combo = exact ? 0 : c->refill > 0 ? 3 : c->refill == 0 ? 0 : c->tuneState >= 4 ? c->tuneChoice
+    const int combo = exact ? 0 : c->refill > 0 ? 3 : c->refill == 0 ? 0 : c->kernelChoice >= 0 ? (c->kernelChoice & 3) : c->tuneState >= 4 ? c->tuneChoice
                     : trial ? kTuneTrial[c->tuneState] : comboDefault;
     const bool refillExtend = (combo & 1) != 0, refillShadow = (combo & 2) != 0;
     const int refillIdle = std::min(64, std::max(1, (int)c->refillIdle));
@@ -422,8 +424,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     }
     // Optional per-kernel-class timing with HIP events on the launch stream (ring of pairs, drained lazily).
     const bool timeKernels = c->timeKernels != 0;
-    double msAcc[3] = {0.0, 0.0, 0.0};
-    uint64_t nLaunch[3] = {0, 0, 0};
+    double msAcc[4] = {0.0, 0.0, 0.0, 0.0};     // 0 closest hit of bounce rays, 1 shading, 2 shadow rays, 3 closest hit of camera rays
+    uint64_t nLaunch[4] = {0, 0, 0, 0};
     size_t evIdx = 0;
     if (timeKernels && c->evRing.empty()) {
         c->evRing.resize(1024);
@@ -464,7 +466,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)qcount, (int)Pp.nslots, 1, st));   // bounce 0: every slot carries a path
         for (uint32_t b = 0; b < maxB; b++) {
             const float4* qin = b == 0 ? nullptr : P.ray[b & 1];       // bounce 0: entry i is slot i, camera rays are regenerated
-            rt_ctx::EvPair* e = evBegin(0);
+            rt_ctx::EvPair* e = evBegin(b == 0 ? 3 : 0);
             if (refillExtend && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
                 const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
                 if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
@@ -537,8 +539,11 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.max_ray_steps = hs.max_ray_steps;
     c->stats.bounce_node_visits = hs.bounce_node_visits; c->stats.bounce_tri_tests = hs.bounce_tri_tests;
     c->stats.wave_node_steps = hs.wave_node_steps; c->stats.wave_tri_steps = hs.wave_tri_steps;
-    c->stats.ms_extend = msAcc[0]; c->stats.ms_shade = msAcc[1]; c->stats.ms_shadow = msAcc[2];
-    c->stats.launches_extend = nLaunch[0]; c->stats.launches_shade = nLaunch[1]; c->stats.launches_shadow = nLaunch[2];
+    c->stats.ms_extend = msAcc[0] + msAcc[3]; c->stats.ms_shade = msAcc[1]; c->stats.ms_shadow = msAcc[2];
+    c->stats.launches_extend = nLaunch[0] + nLaunch[3]; c->stats.launches_shade = nLaunch[1]; c->stats.launches_shadow = nLaunch[2];
+    c->stats.ms_extend_primary = msAcc[3]; c->stats.launches_extend_primary = nLaunch[3];
+    c->stats.kernel_choice = exact ? -2 : combo;
+    c->stats.kernel_choice_settled = (exact || c->refill >= 0 || c->kernelChoice >= 0 || c->tuneState >= 4) ? 1 : 0;
     c->primValid = aov;
     return RT_OK;
 }
@@ -673,6 +678,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
     else if (name_is(name, "refillNodeMin")) c->refillNodeMin = v;
     else if (name_is(name, "sunKernel")) c->sunKernel = v;
+    else if (name_is(name, "kernelChoice")) c->kernelChoice = v < 0 ? -1 : (v & 3);
     else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 0 ? 0 : v;
     else if (name_is(name, "autoPass")) c->autoPass = v;
     else if (name_is(name, "passStreams")) c->passStreams = v < 1 ? 4 : v;      // < 1: back to the default

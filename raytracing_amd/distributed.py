@@ -50,6 +50,27 @@ def reduce_color(color_tensor, dst=0):
     return color_tensor
 
 
+def agree_on_kernels(cs, src=0):
+    """Every rank of a job runs the traversal kernels rank `src` settled on.  The library picks them per scene from four
+    host-clocked trial frames (rt_core.h, refill), so two ranks could decide differently: images would still be identical,
+    but shard times, and with them the frame time (the slowest rank's), would not.  The choice (rt_stats.kernel_choice of
+    the last render, -1 if that rank's trial has not finished) travels through the existing process group as one integer;
+    a settled choice is then pinned on every rank with rt_set_int("kernelChoice").  Returns the choice, or -1."""
+    import torch
+    import torch.distributed as dist
+    st = cs.stats()
+    mine = int(st["kernel_choice"]) if st.get("kernel_choice_settled") and st["kernel_choice"] >= 0 else -1
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return mine
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([mine], dtype=torch.int32, device=dev)
+    dist.broadcast(t, src=src)
+    choice = int(t.item())
+    if choice >= 0:
+        cs.setInt("kernelChoice", choice)
+    return choice
+
+
 class DeviceImage:
     """Zero-copy torch view of a core image (W*H*4 floats in HBM) through __cuda_array_interface__."""
 

@@ -66,7 +66,7 @@ def main(argv=None):
             dist.init_process_group(args.backend)
     from . import ComputeShader
     from . import scene as S
-    from .distributed import render_frame_distributed
+    from .distributed import agree_on_kernels, render_frame_distributed
 
     cs = ComputeShader(device=local, rank=rank, world_size=world)
     S.Scene.LoadScene(cs, args.scene, args.models)
@@ -80,6 +80,7 @@ def main(argv=None):
 
     frames = range(args.first_frame, args.first_frame + args.frames)
     rays = 0
+    agreed = False
     from concurrent.futures import ThreadPoolExecutor
     pool, pending = ThreadPoolExecutor(max_workers=1), []
     if world > 1:
@@ -98,6 +99,8 @@ def main(argv=None):
             render_frame_distributed(cs, args.spp, rank, world, args.band_ranks)
             writer = rank == 0
         st = cs.stats()
+        if world > 1 and args.split == "samples" and not agreed and f - args.first_frame >= 4:
+            agreed = agree_on_kernels(cs) >= 0        # once rank 0's per-scene trial has finished, every rank runs its choice
         rays += st["rays_primary"] + st["rays_bounce"] + st["rays_shadow"]
         if out_dir and writer:
             # the 8-bit frame is converted on the GPU and read back here; the file is written by a worker thread while

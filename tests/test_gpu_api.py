@@ -290,13 +290,16 @@ def test_full_size_frame_is_reproducible_and_stream_independent(oracle_lib, scen
     assert st["rays_primary"] == W * H * spp
     cs.dispatch()
     assert np.array_equal(bits(cs.get_image(0)), bits(first))
-    for knobs in ({"passStreams": 1}, {"passStreams": 3, "samplesPerPass": 7, "autoPass": 0}, {"refill": 1}, {"blocksPerCU": 5}):
+    for knobs in ({"passStreams": 1}, {"passStreams": 3, "samplesPerPass": 7, "autoPass": 0}, {"refill": 1}, {"blocksPerCU": 5},
+                  {"kernelChoice": 2}, {"kernelChoice": 1}):
         for k, v in knobs.items():
             cs.setInt(k, v)
         cs.dispatch()
         assert np.array_equal(bits(cs.get_image(0)), bits(first)), knobs
+        if "kernelChoice" in knobs:      # the pinned combination is the one that ran, and is reported back (multi-GPU jobs pin rank 0's)
+            assert cs.stats()["kernel_choice"] == knobs["kernelChoice"] and cs.stats()["kernel_choice_settled"] == 1
         for k in knobs:
-            cs.setInt(k, {"passStreams": 0, "samplesPerPass": 64, "autoPass": 1, "refill": -1, "blocksPerCU": 64}[k])
+            cs.setInt(k, {"passStreams": 0, "samplesPerPass": 64, "autoPass": 1, "refill": -1, "blocksPerCU": 64, "kernelChoice": -1}[k])
     cs.Delete()
 
 
