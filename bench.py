@@ -223,7 +223,9 @@ def main():
         # samples of the same frame; per-ray averages x rays of the timed launches / their measured duration.
         cs.setInt("timeKernels", 0)
         cs.setInt("countVisits", 1)
-        cs.dispatch_region(0, 0, W, H, 0, min(4, args.spp))
+        # (one full pass of the samples the timed frames trace together, library default 64: queue lengths per launch, and
+        # with them how often a persistent wave can refill its lanes, are then those of the timed launches)
+        cs.dispatch_region(0, 0, W, H, 0, min(args.samples_per_pass or 64, args.spp))
         c = cs.stats()
         cs.setInt("countVisits", 0)
         ext_rays_c = c["rays_primary"] + c["rays_bounce"]

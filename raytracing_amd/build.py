@@ -19,16 +19,22 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, out=None, extra_flags=()):
+    """out / extra_flags: an experimental variant of the library beside the product build (kernel A/B runs load it through
+    the RT_CORE_LIB environment variable, raytracing_amd/_lib.py); never what the tests or the bench load by default."""
+    if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread"]
+    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", out or LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":
-    build(force=True, verbose=True)
+    import sys
+    if len(sys.argv) > 1:      # python -m raytracing_amd.build <variant.so> -DRT_EXP_...   (experimental variant)
+        build(force=True, verbose=True, out=os.path.abspath(sys.argv[1]), extra_flags=sys.argv[2:])
+    else:
+        build(force=True, verbose=True)

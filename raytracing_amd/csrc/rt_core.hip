@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,10 +29,10 @@ struct Texture { DevBuf data; uint32_t w = 0, h = 0; };
 // Everything rt_trace_rays keeps in hipMalloc'ed buffers (ray queue, hit records, queue counter, traversal-stack
 // overflow, staged inputs and outputs) lives in this file-scope array for the allocation-free variant.  Each GPU the
 // library runs on holds its own copy until the process ends.  Layout for n rays (offsets in bytes, all 256-aligned):
-//   [0, 256)  queue counter + DeviceStats | rays 32 n | hits 8 n | origins 12 n | dirs 12 n | tri ids 4 n | hit locs 12 n |
+//   [0, 512)  queue counter + DeviceStats | rays 32 n | hits 8 n | origins 12 n | dirs 12 n | tri ids 4 n | hit locs 12 n |
 //   stack overflow 8 x RT_SPILL_STACK x n (the deepest tree the shader's 64-entry stack can hold)
 constexpr uint64_t kNoAllocMaxRays = RT_NOALLOC_MAX_RAYS;
-constexpr uint64_t kScratchHeader = 256;
+constexpr uint64_t kScratchHeader = 512;
 constexpr uint64_t kScratchBytes = kScratchHeader + kNoAllocMaxRays * (32 + 8 + 12 + 12 + 4 + 12 + 8ull * RT_SPILL_STACK) + 7 * 256;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 // `scratch` is a host-side stand-in in host code, not a device address: the address of each device's copy is looked up
@@ -82,7 +83,8 @@ struct rt_ctx {
     hipEvent_t evResolve[kMaxSets] = {}, evInit = nullptr;
     int32_t passStreams = 4, autoPass = 1;
     // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill 0 = never, 1 = always, -1 = chosen per scene.
-    int32_t refill = -1, refillIdle = 16, refillNodeMin = 28, refillBlocksPerCU = 0;   // refillBlocksPerCU 0 = automatic (refill_blocks)
+    int32_t refill = -1, refillIdle = 16, refillNodeMin = 28, refillBlocksPerCU = 0;
+    int32_t refillTriMin = 0, refillNodeLow = 0, refillDefer = 0;   // 0 = the kernels' defaults (rt_trace_refill.hip.h, RefillSched)   // refillBlocksPerCU 0 = automatic (refill_blocks)
     // refill = -1: which traversal kernels are faster depends on the scene, and not the same way for closest-hit and
     // shadow rays (scene 7: closest hit +14 % with refill, one-sun shadow rays -5 %; scene 4: batch for both; the
     // 20 M-triangle field: refill for both), so the first four sizeable frames after a scene upload are rendered with
@@ -414,7 +416,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                     : trial ? kTuneTrial[c->tuneState] : comboDefault;
     const bool refillExtend = (combo & 1) != 0, refillShadow = (combo & 2) != 0;
     const int refillIdle = std::min(64, std::max(1, (int)c->refillIdle));
-    const int refillNodeMin = std::min(64, std::max(1, (int)c->refillNodeMin));
+    const int refillNodeMin = std::min(64, std::max(1, (int)c->refillNodeMin)) | (std::min(64, std::max(0, (int)c->refillTriMin)) << 8) |
+                              (std::min(64, std::max(0, (int)c->refillNodeLow)) << 16) | ((c->refillDefer != 0 ? 1 : 0) << 24);
     hipStream_t streams[rt_ctx::kMaxSets];
     streams[0] = c->stream;
     for (int k = 1; k < rt_ctx::kMaxSets; k++) streams[k] = c->extra[k];
@@ -535,6 +538,20 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             }
         }
     }
+    if (count && std::getenv("RT_DEBUG"))
+        std::fprintf(stderr, "[rt] refill census: node-phase exits %llu, parked lanes/exit %.2f, free lanes/exit %.2f; reasons: parked>=triMin %llu, few nodes %llu, refill %llu, no nodes %llu; deferred %llu\n",
+                     hs.dbg[0], hs.dbg[0] ? (double)hs.dbg[1] / hs.dbg[0] : 0.0, hs.dbg[0] ? (double)hs.dbg[7] / hs.dbg[0] : 0.0, hs.dbg[2], hs.dbg[3], hs.dbg[5], hs.dbg[6], hs.dbg[4]);
+    if (std::getenv("RT_DEBUG")) {
+        std::vector<uint32_t> qc(2 * (maxB + 1));
+        if (hipMemcpy(qc.data(), Pset[0].counters, qc.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            std::fprintf(stderr, "[rt] queue sizes of the last pass on set 0 (paths / shadow rays per bounce), max ray steps %llu:", hs.max_ray_steps);
+            for (uint32_t b = 0; b < maxB; b++) std::fprintf(stderr, " %u/%u", qc[b], qc[maxB + 1 + b]);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    if (count && std::getenv("RT_DEBUG"))
+        std::fprintf(stderr, "[rt] steps with no refill possible: node %llu (lanes/step %.1f) of %llu, tri %llu (lanes/step %.1f) of %llu\n",
+                     hs.dbg2[0], hs.dbg2[0] ? (double)hs.dbg2[1] / hs.dbg2[0] : 0.0, hs.wave_node_steps, hs.dbg2[2], hs.dbg2[2] ? (double)hs.dbg2[3] / hs.dbg2[2] : 0.0, hs.wave_tri_steps);
     c->stats.shadow_node_visits = hs.shadow_node_visits; c->stats.shadow_tri_tests = hs.shadow_tri_tests;
     c->stats.max_ray_steps = hs.max_ray_steps;
     c->stats.bounce_node_visits = hs.bounce_node_visits; c->stats.bounce_tri_tests = hs.bounce_tri_tests;
@@ -677,6 +694,9 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
     else if (name_is(name, "refillNodeMin")) c->refillNodeMin = v;
+    else if (name_is(name, "refillTriMin")) c->refillTriMin = v;
+    else if (name_is(name, "refillNodeLow")) c->refillNodeLow = v;
+    else if (name_is(name, "refillDefer")) c->refillDefer = v;
     else if (name_is(name, "sunKernel")) c->sunKernel = v;
     else if (name_is(name, "kernelChoice")) c->kernelChoice = v < 0 ? -1 : (v & 3);
     else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 0 ? 0 : v;

@@ -52,7 +52,12 @@ __device__ __forceinline__ void unpack_ray(float4 a, float4 b, v3& o, v3& d, uin
 // wave64 ballot + mbcnt prefix inside each wave, wave totals combined through LDS, ONE atomic per queue per
 // block (a single counter word sustains only ~88 atomics/us on MI355X, so per-wave atomics would bound the
 // kernel).  Returns the output index of item k of this thread in idx[q][k] (valid where flag set).
+#ifndef RT_ITEMS
 #define RT_ITEMS 4
+#endif
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 1
+#endif
 template <int NQ>
 __device__ __forceinline__ void block_append(const bool (&flag)[NQ][RT_ITEMS], uint32_t* const (&counter)[NQ],
                                              uint32_t (&idx)[NQ][RT_ITEMS], uint32_t* ldsScratch /* >= NQ*8 words */) {
@@ -541,6 +546,217 @@ __device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float a
     return H / lenH;
 }
 
+// shader.comp:329-452 and 524-531 for ONE path whose closest hit is h2 = (t, reference triangle id; -1 miss, -2 dead slot):
+// miss / ambient, surface fetch, dielectric / GGX bounce, the light loop's contributions into the log (entries that await a
+// shadow ray get w = 1).  In: the ray that was traced (rayLoc, rayDir), the path's strength and refraction flag.  Out: the
+// next ray and strength, cont (the path goes on to bounce + 1), wantShadow (a log entry awaits its shadow ray, whose origin
+// is the new rayLoc).  hitLoc = rayLoc + rayDir * t, formed by the caller.
+struct ShadeResult { v3 o, d, s; bool refracting, cont, wantShadow; uint32_t pending, skipped; };
+template <bool TEX, bool GLASS, bool MANY, bool SUN1>
+__device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const FrameParams& F, const PathBuffers& P, int bounce, int px, int py, int r,
+                                                  uint32_t slot, float2 h2, v3 rayLoc, v3 rayDir, v3 strength, bool refracting, const v3 hitLoc,
+                                                  float4* imgAlbedo, float4* imgNormal, float4* imgDepth, int32_t* primTri, float* primHit) {
+    bool cont = false, wantShadow = false;
+    uint32_t pending = 0, skipped = 0;
+    int ref = __float_as_int(h2.y);
+    v3 camPos = ld3(F.camPos);
+    float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;   // entry of light l at logp[l * nslots]
+    if (ref == -2) {
+        // dead slot (edge tile outside the region)
+    } else if (ref < 0) {
+        // miss: shader.comp:331-336
+        v3 ambient = F.hasSun ? mk(0.4431372549f, 0.73725490196f, 1.f) : mk(0.f, 0.f, 0.f);
+        v3 cc = ambient * strength;
+        logp[0] = make_float4(cc.x, cc.y, cc.z, 2.f);
+        for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * P.nslots] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r == 0 && bounce == 0 && primTri) primTri[(size_t)py * F.width + px] = -1;
+    } else {
+        const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
+        const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4];
+        v3 a = mk(q0.x, q0.y, q0.z), b = mk(q0.w, q1.x, q1.y), c = mk(q1.z, q1.w, q2.x);
+        v3 n1 = mk(q2.y, q2.z, q2.w), n2 = mk(q3.x, q3.y, q3.z), n3 = mk(q3.w, q4.x, q4.y);
+        uint32_t matIdx = __float_as_uint(q4.z);
+        const float4* m4 = reinterpret_cast<const float4*>(S.cmat + matIdx);
+        float4 m0 = m4[0], m1 = m4[1];
+        const uint32_t mflags = TEX ? __float_as_uint(m1.w) : 0u;
+        const bool hasBase = (mflags & 1u) != 0u, hasNormal = (mflags & 2u) != 0u, hasMR = (mflags & 4u) != 0u;
+        float uv1x = 0.f, uv1y = 0.f, uv2x = 0.f, uv2y = 0.f, uv3x = 0.f, uv3y = 0.f;
+        float4 q6 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mflags != 0u) {          // UVs and vertex ids only matter to textured / normal-mapped materials
+            const float4* up = reinterpret_cast<const float4*>(S.shadeUV + ref);
+            float4 u0 = up[0], u1 = up[1], u2 = up[2];
+            uv1x = u0.x; uv1y = u0.y; uv2x = u0.z; uv2y = u0.w; uv3x = u1.x; uv3y = u1.y;
+            q6 = make_float4(0.f, u1.z, u1.w, u2.x);
+        }
+        // barycentric, shader.comp:132-151
+        v3 v0 = b - a, v1 = c - a, v2 = hitLoc - a;
+        float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
+        float denomB = d00 * d11 - d01 * d01;
+        float bv = (d11 * d20 - d01 * d21) / denomB;
+        float bw = (d00 * d21 - d01 * d20) / denomB;
+        float bu = 1.0f - bv - bw;
+        v3 hitNormal = (n1 * bu + n2 * bv + n3 * bw);
+        float hitU = uv1x * bu + uv2x * bv + uv3x * bw;
+        float hitV = uv1y * bu + uv2y * bv + uv3y * bw;
+        const RefMaterial* mp = S.materials + matIdx;        // texture handles (read only under a flag)
+        float transmission = m0.w, ior = m1.z;
+        float metallicFactor, roughnessFactor;
+        if (hasMR) {
+            float4 t = sample_tex(S, mp->metallicRoughnessTexture, hitU, hitV);
+            metallicFactor = t.x; roughnessFactor = t.y;
+        } else { metallicFactor = m1.x; roughnessFactor = m1.y; }
+        v3 normal;
+        if (hasNormal) {
+            uint32_t i1 = __float_as_uint(q6.y), i2 = __float_as_uint(q6.z), i3 = __float_as_uint(q6.w);
+            const float* t1 = S.vertices[i1].tangent; const float* t2 = S.vertices[i2].tangent; const float* t3 = S.vertices[i3].tangent;
+            v3 tangent = (ld3(t1) * bu + ld3(t2) * bv + ld3(t3) * bw);
+            float handed = t1[3] * bu + t2[3] * bv + t3[3] * bw;
+            float4 nt = sample_tex(S, mp->normalTexture, hitU, hitV);
+            v3 normalTex = mk(nt.x, nt.y, nt.z) * 2.0f - mk(1.f, 1.f, 1.f);
+            float normalStrength = 1.f;
+            normalTex.x *= normalStrength; normalTex.y *= normalStrength;
+            v3 bitangent = cross3(hitNormal, tangent) * handed;
+            normal = tangent * normalTex.x + bitangent * normalTex.y + hitNormal * normalTex.z;
+        } else normal = hitNormal;
+
+        // reflect / refract, shader.comp:389-431
+        bool shouldReflect = true;
+        float rb = (float)(r * bounce);
+        if (GLASS && transmission > 0) {
+            float iorAir = 1.f;
+            float cosi = gclamp(dot3(-rayDir, normal), -1.0f, 1.0f);
+            float r0 = (iorAir - ior) / (iorAir + ior);
+            r0 = r0 * r0;
+            float reflectionStrength = r0 + (1.0f - r0) * pow5(1.0f - cosi);
+            if (!refracting) {
+                float rnd = hash13(mk((float)px * 2.3f, (float)py * 2.3f, rb * 18.f) * rayDir + rayLoc);
+                if (rnd > reflectionStrength) {
+                    rayDir = refract3(rayDir, normal, iorAir / ior);
+                    rayLoc = hitLoc - normal * 1e-5f;
+                    strength = strength * transmission;
+                    refracting = true;
+                    shouldReflect = false;
+                }
+            } else {
+                v3 newLoc = hitLoc + normal * 1e-5f;
+                v3 newDir = refract3(rayDir, -normal, ior / iorAir);
+                if (length3(newDir) == 0.f) {
+                    rayDir = reflect3(rayDir, -normal);
+                    rayLoc = hitLoc - normal * 1e-5f;
+                    refracting = true;
+                } else {
+                    rayLoc = newLoc;
+                    rayDir = newDir;
+                    refracting = false;
+                }
+                shouldReflect = false;
+            }
+        }
+        if (shouldReflect) {
+            v3 H = normal;                       // sampleGGX returns N for alpha == 0 (shader.comp:194): no hashes needed
+            if (roughnessFactor != 0.f) {
+                float h1 = hash13(mk((float)px, (float)py, rb) * rayDir + rayLoc);
+                float h2 = hash13(mk((float)px * 37.f, (float)py * 37.f, rb * 37.f) * rayDir + rayLoc);
+                H = sample_ggx(normal, h1, h2, roughnessFactor);
+            }
+            rayDir = reflect3(rayDir, H);
+            rayLoc = hitLoc + (normal * 1e-5f);
+        }
+
+        // lighting set-up, shader.comp:433-451
+        v3 baseColor = mk(m0.x, m0.y, m0.z);
+        if (hasBase) {
+            float4 t = sample_tex(S, mp->baseColorTexture, hitU, hitV);
+            baseColor = mk(t.x, t.y, t.z);
+        }
+        v3 viewDir = normalize3(camPos - hitLoc);
+        float dielectricF0 = .04f;
+        if (GLASS && transmission > 0) { float e = (ior - 1.0f) / (ior + 1.0f); dielectricF0 = e * e; }
+        v3 F0 = mk(dielectricF0, dielectricF0, dielectricF0) * (1.0f - metallicFactor) + baseColor * metallicFactor;
+        float alpha = roughnessFactor * roughnessFactor;
+        const float PI = 3.14159265359f;
+        v3 diffuseColor = baseColor * (1.0f - metallicFactor);
+
+        if (r == 0 && bounce == 0) {
+            size_t pix = (size_t)py * F.width + px;
+            if (imgAlbedo) {
+                imgAlbedo[pix] = make_float4(diffuseColor.x, diffuseColor.y, diffuseColor.z, 1.f);
+                imgNormal[pix] = make_float4(normal.x / 2.f + 0.5f, normal.y / 2.f + 0.5f, normal.z / 2.f + 0.5f, 1.f);
+                float dd = length3(camPos - hitLoc) / 255.f;
+                imgDepth[pix] = make_float4(dd, dd, dd, 1.f);
+            }
+            if (primTri) {
+                primTri[pix] = ref;
+                primHit[pix * 3] = hitLoc.x; primHit[pix * 3 + 1] = hitLoc.y; primHit[pix * 3 + 2] = hitLoc.z;
+            }
+        }
+
+        // light loop, shader.comp:453-522 minus the shadow lineCast (k_shadow)
+        if (!SUN1 && F.numLights == 0) logp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int nLightsHere = SUN1 ? 1 : F.numLights;
+        for (int l = 0; l < nLightsHere; l++) {
+            const RefLight Lg = MANY ? light_at(S, F, l) : F.lights[l];
+            float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, __uint_as_float(Lg.lightType)), L2 = make_float4(Lg.color.x, Lg.color.y, Lg.color.z, 0.f);
+            const uint32_t ltype = SUN1 ? 1u : __float_as_uint(L1.w);
+            v3 dirToLight = mk(0.f, 0.f, 0.f);
+            float attenuation = 1.f;
+            bool cast = false;
+            if (ltype == 0u) {
+                v3 toL = mk(L0.x, L0.y, L0.z) - hitLoc;
+                dirToLight = normalize3(toL);
+                float distToLight = length3(toL);
+                attenuation = L0.w / (1.f + 1.f * distToLight + 1.f * distToLight * distToLight);
+                cast = true;
+            } else if (ltype == 1u) {
+                dirToLight = -mk(L1.x, L1.y, L1.z);
+                cast = true;
+            }
+            float NdotL = gmax(dot3(normal, dirToLight), 0.0f);
+            float4 pendOut = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(NdotL <= 0.0f)) {
+                v3 Hh = normalize3(viewDir + dirToLight);
+                float NdotH = gmax(dot3(normal, Hh), 0.0f);
+                float NdotV = gmax(dot3(normal, viewDir), 0.0f);
+                float cosTheta = gclamp(dot3(normal, -viewDir), 0.0f, 1.0f);
+                v3 Fr = F0 + (1.0f - F0) * pow5(1.0f - cosTheta);
+                float a2 = alpha * alpha;
+                float denom = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
+                float D = a2 / (PI * denom * denom);
+                float k = (alpha + 1) * (alpha + 1) / 8.0f;
+                float G_V = NdotV / (NdotV * (1.0f - k) + k);
+                float G_L = NdotL / (NdotL * (1.0f - k) + k);
+                float G = G_V * G_L;
+                v3 specular = (D * Fr * G) / (4.0f * NdotV * NdotL + 0.001f);
+                v3 diffuse = diffuseColor / PI;
+                v3 radiance = mk(L2.x, L2.y, L2.z) * attenuation;
+                v3 contrib = (diffuse + specular) * radiance * NdotL * strength;
+                // A contribution of exactly +-0 in all three channels (mirror metals: diffuse 0 and D = 0) leaves
+                // the pixel sum unchanged bit for bit whether or not it is added (the sum starts at +0 and
+                // x + (+-0) == x), so the shadow ray that would decide it is not traced.  NaN fails the test.
+                const bool nothing = cast && contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f;
+                if (nothing) skipped++;
+                else {
+                    pendOut = make_float4(contrib.x, contrib.y, contrib.z, cast ? 1.f : 2.f);
+                    if (cast) { wantShadow = true; pending++; }
+                }
+                // cast == false: a light type the shader does not know gets no shadow test and its
+                // contribution (only reachable with a NaN normal) is added directly: w = 2
+            } else if (cast) skipped++;
+            logp[(size_t)l * P.nslots] = pendOut;
+        }
+
+        // shader.comp:524-530
+        if (transmission == 0.f)
+            strength = strength * mk(gclamp(baseColor.x, 0.f, 1.f), gclamp(baseColor.y, 0.f, 1.f), gclamp(baseColor.z, 0.f, 1.f));
+        bool active = !(length3(strength) < F.strengthCutoff);
+        cont = active && (bounce + 1 < F.maxBounces);
+    }
+    ShadeResult R;
+    R.o = rayLoc; R.d = rayDir; R.s = strength; R.refracting = refracting; R.cont = cont; R.wantShadow = wantShadow;
+    R.pending = pending; R.skipped = skipped;
+    return R;
+}
+
 // shader.comp:329-452 and 524-531 for one path; light loop body 486-521 is evaluated here and its
 // result parked in `pend` until k_shadow has traced the shadow ray (453-484).
 // TEX / GLASS: the scene has a textured (or normal-mapped) material / a transmissive one.  Scenes without them run a
@@ -548,7 +764,7 @@ __device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float a
 // the kernel arguments (RT_MAX_LIGHTS); otherwise every light is a scalar kernarg read.  SUN1: exactly one light and it is
 // a sun (every BASELINE config): no light loop, no point-light branch.
 template <bool TEX, bool GLASS, bool MANY, bool SUN1>
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, PathBuffers P,
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(SceneView S, FrameParams F, PathBuffers P,
                                                     const uint32_t* __restrict__ count, uint32_t* countOut,
                                                     uint32_t* shadowCountOut, int rBase, int bounce,
                                                     float4* imgAlbedo, float4* imgNormal, float4* imgDepth,
@@ -575,16 +791,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
     uint32_t skipped = 0, pending = 0;
     for (uint32_t ch = blockIdx.x; ch < nChunks; ch += gridDim.x) {
       uint32_t contMask = 0, shadowMask = 0, refrMask = 0;
-      uint32_t slotK[RT_ITEMS] = {0u, 0u, 0u, 0u};
+      uint32_t slotK[RT_ITEMS] = {};
       const uint32_t iBase = ch * chunk + threadIdx.x;
       const float2 noHit = make_float2(0.f, __int_as_float(-2));
       float2 hq0 = noHit, hq1 = noHit, hq2 = noHit, hq3 = noHit;
-      static_assert(RT_ITEMS == 4, "hit-record queue below holds four items");
+      static_assert(RT_ITEMS >= 1 && RT_ITEMS <= 4, "hit-record queue below holds up to four items");
       if (PF) {
           if (iBase < n) hq0 = P.hit[iBase];
-          if (iBase + RT_BLOCK < n) hq1 = P.hit[iBase + RT_BLOCK];
-          if (iBase + 2 * RT_BLOCK < n) hq2 = P.hit[iBase + 2 * RT_BLOCK];
-          if (iBase + 3 * RT_BLOCK < n) hq3 = P.hit[iBase + 3 * RT_BLOCK];
+          if (RT_ITEMS > 1 && iBase + RT_BLOCK < n) hq1 = P.hit[iBase + RT_BLOCK];
+          if (RT_ITEMS > 2 && iBase + 2 * RT_BLOCK < n) hq2 = P.hit[iBase + 2 * RT_BLOCK];
+          if (RT_ITEMS > 3 && iBase + 3 * RT_BLOCK < n) hq3 = P.hit[iBase + 3 * RT_BLOCK];
       }
 #pragma unroll 1
       for (int item = 0; item < RT_ITEMS; item++) {
@@ -614,198 +830,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView S, FrameParams F, 
                 slot_to_pixel(F, slot % P.slotsPerSample, &px, &py);
             }
             int ref = __float_as_int(h2.y);
-            v3 camPos = ld3(F.camPos);
-            float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;   // entry of light l at logp[l * nslots]
-            if (ref == -2) {
-                // dead slot (edge tile outside the region)
-            } else if (ref < 0) {
-                // miss: shader.comp:331-336
-                v3 ambient = F.hasSun ? mk(0.4431372549f, 0.73725490196f, 1.f) : mk(0.f, 0.f, 0.f);
-                v3 cc = ambient * strength;
-                logp[0] = make_float4(cc.x, cc.y, cc.z, 2.f);
-                for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * P.nslots] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r == 0 && bounce == 0 && primTri) primTri[(size_t)py * F.width + px] = -1;
-            } else {
-                v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122)
-                const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
-                const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4];
-                v3 a = mk(q0.x, q0.y, q0.z), b = mk(q0.w, q1.x, q1.y), c = mk(q1.z, q1.w, q2.x);
-                v3 n1 = mk(q2.y, q2.z, q2.w), n2 = mk(q3.x, q3.y, q3.z), n3 = mk(q3.w, q4.x, q4.y);
-                uint32_t matIdx = __float_as_uint(q4.z);
-                const float4* m4 = reinterpret_cast<const float4*>(S.cmat + matIdx);
-                float4 m0 = m4[0], m1 = m4[1];
-                const uint32_t mflags = TEX ? __float_as_uint(m1.w) : 0u;
-                const bool hasBase = (mflags & 1u) != 0u, hasNormal = (mflags & 2u) != 0u, hasMR = (mflags & 4u) != 0u;
-                float uv1x = 0.f, uv1y = 0.f, uv2x = 0.f, uv2y = 0.f, uv3x = 0.f, uv3y = 0.f;
-                float4 q6 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mflags != 0u) {          // UVs and vertex ids only matter to textured / normal-mapped materials
-                    const float4* up = reinterpret_cast<const float4*>(S.shadeUV + ref);
-                    float4 u0 = up[0], u1 = up[1], u2 = up[2];
-                    uv1x = u0.x; uv1y = u0.y; uv2x = u0.z; uv2y = u0.w; uv3x = u1.x; uv3y = u1.y;
-                    q6 = make_float4(0.f, u1.z, u1.w, u2.x);
-                }
-                // barycentric, shader.comp:132-151
-                v3 v0 = b - a, v1 = c - a, v2 = hitLoc - a;
-                float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
-                float denomB = d00 * d11 - d01 * d01;
-                float bv = (d11 * d20 - d01 * d21) / denomB;
-                float bw = (d00 * d21 - d01 * d20) / denomB;
-                float bu = 1.0f - bv - bw;
-                v3 hitNormal = (n1 * bu + n2 * bv + n3 * bw);
-                float hitU = uv1x * bu + uv2x * bv + uv3x * bw;
-                float hitV = uv1y * bu + uv2y * bv + uv3y * bw;
-                const RefMaterial* mp = S.materials + matIdx;        // texture handles (read only under a flag)
-                float transmission = m0.w, ior = m1.z;
-                float metallicFactor, roughnessFactor;
-                if (hasMR) {
-                    float4 t = sample_tex(S, mp->metallicRoughnessTexture, hitU, hitV);
-                    metallicFactor = t.x; roughnessFactor = t.y;
-                } else { metallicFactor = m1.x; roughnessFactor = m1.y; }
-                v3 normal;
-                if (hasNormal) {
-                    uint32_t i1 = __float_as_uint(q6.y), i2 = __float_as_uint(q6.z), i3 = __float_as_uint(q6.w);
-                    const float* t1 = S.vertices[i1].tangent; const float* t2 = S.vertices[i2].tangent; const float* t3 = S.vertices[i3].tangent;
-                    v3 tangent = (ld3(t1) * bu + ld3(t2) * bv + ld3(t3) * bw);
-                    float handed = t1[3] * bu + t2[3] * bv + t3[3] * bw;
-                    float4 nt = sample_tex(S, mp->normalTexture, hitU, hitV);
-                    v3 normalTex = mk(nt.x, nt.y, nt.z) * 2.0f - mk(1.f, 1.f, 1.f);
-                    float normalStrength = 1.f;
-                    normalTex.x *= normalStrength; normalTex.y *= normalStrength;
-                    v3 bitangent = cross3(hitNormal, tangent) * handed;
-                    normal = tangent * normalTex.x + bitangent * normalTex.y + hitNormal * normalTex.z;
-                } else normal = hitNormal;
-
-                // reflect / refract, shader.comp:389-431
-                bool shouldReflect = true;
-                float rb = (float)(r * bounce);
-                if (GLASS && transmission > 0) {
-                    float iorAir = 1.f;
-                    float cosi = gclamp(dot3(-rayDir, normal), -1.0f, 1.0f);
-                    float r0 = (iorAir - ior) / (iorAir + ior);
-                    r0 = r0 * r0;
-                    float reflectionStrength = r0 + (1.0f - r0) * pow5(1.0f - cosi);
-                    if (!refracting) {
-                        float rnd = hash13(mk((float)px * 2.3f, (float)py * 2.3f, rb * 18.f) * rayDir + rayLoc);
-                        if (rnd > reflectionStrength) {
-                            rayDir = refract3(rayDir, normal, iorAir / ior);
-                            rayLoc = hitLoc - normal * 1e-5f;
-                            strength = strength * transmission;
-                            refracting = true;
-                            shouldReflect = false;
-                        }
-                    } else {
-                        v3 newLoc = hitLoc + normal * 1e-5f;
-                        v3 newDir = refract3(rayDir, -normal, ior / iorAir);
-                        if (length3(newDir) == 0.f) {
-                            rayDir = reflect3(rayDir, -normal);
-                            rayLoc = hitLoc - normal * 1e-5f;
-                            refracting = true;
-                        } else {
-                            rayLoc = newLoc;
-                            rayDir = newDir;
-                            refracting = false;
-                        }
-                        shouldReflect = false;
-                    }
-                }
-                if (shouldReflect) {
-                    v3 H = normal;                       // sampleGGX returns N for alpha == 0 (shader.comp:194): no hashes needed
-                    if (roughnessFactor != 0.f) {
-                        float h1 = hash13(mk((float)px, (float)py, rb) * rayDir + rayLoc);
-                        float h2 = hash13(mk((float)px * 37.f, (float)py * 37.f, rb * 37.f) * rayDir + rayLoc);
-                        H = sample_ggx(normal, h1, h2, roughnessFactor);
-                    }
-                    rayDir = reflect3(rayDir, H);
-                    rayLoc = hitLoc + (normal * 1e-5f);
-                }
-
-                // lighting set-up, shader.comp:433-451
-                v3 baseColor = mk(m0.x, m0.y, m0.z);
-                if (hasBase) {
-                    float4 t = sample_tex(S, mp->baseColorTexture, hitU, hitV);
-                    baseColor = mk(t.x, t.y, t.z);
-                }
-                v3 viewDir = normalize3(camPos - hitLoc);
-                float dielectricF0 = .04f;
-                if (GLASS && transmission > 0) { float e = (ior - 1.0f) / (ior + 1.0f); dielectricF0 = e * e; }
-                v3 F0 = mk(dielectricF0, dielectricF0, dielectricF0) * (1.0f - metallicFactor) + baseColor * metallicFactor;
-                float alpha = roughnessFactor * roughnessFactor;
-                const float PI = 3.14159265359f;
-                v3 diffuseColor = baseColor * (1.0f - metallicFactor);
-
-                if (r == 0 && bounce == 0) {
-                    size_t pix = (size_t)py * F.width + px;
-                    if (imgAlbedo) {
-                        imgAlbedo[pix] = make_float4(diffuseColor.x, diffuseColor.y, diffuseColor.z, 1.f);
-                        imgNormal[pix] = make_float4(normal.x / 2.f + 0.5f, normal.y / 2.f + 0.5f, normal.z / 2.f + 0.5f, 1.f);
-                        float dd = length3(camPos - hitLoc) / 255.f;
-                        imgDepth[pix] = make_float4(dd, dd, dd, 1.f);
-                    }
-                    if (primTri) {
-                        primTri[pix] = ref;
-                        primHit[pix * 3] = hitLoc.x; primHit[pix * 3 + 1] = hitLoc.y; primHit[pix * 3 + 2] = hitLoc.z;
-                    }
-                }
-
-                // light loop, shader.comp:453-522 minus the shadow lineCast (k_shadow)
-                if (!SUN1 && F.numLights == 0) logp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int nLightsHere = SUN1 ? 1 : F.numLights;
-                for (int l = 0; l < nLightsHere; l++) {
-                    const RefLight Lg = MANY ? light_at(S, F, l) : F.lights[l];
-                    float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, __uint_as_float(Lg.lightType)), L2 = make_float4(Lg.color.x, Lg.color.y, Lg.color.z, 0.f);
-                    const uint32_t ltype = SUN1 ? 1u : __float_as_uint(L1.w);
-                    v3 dirToLight = mk(0.f, 0.f, 0.f);
-                    float attenuation = 1.f;
-                    bool cast = false;
-                    if (ltype == 0u) {
-                        v3 toL = mk(L0.x, L0.y, L0.z) - hitLoc;
-                        dirToLight = normalize3(toL);
-                        float distToLight = length3(toL);
-                        attenuation = L0.w / (1.f + 1.f * distToLight + 1.f * distToLight * distToLight);
-                        cast = true;
-                    } else if (ltype == 1u) {
-                        dirToLight = -mk(L1.x, L1.y, L1.z);
-                        cast = true;
-                    }
-                    float NdotL = gmax(dot3(normal, dirToLight), 0.0f);
-                    float4 pendOut = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!(NdotL <= 0.0f)) {
-                        v3 Hh = normalize3(viewDir + dirToLight);
-                        float NdotH = gmax(dot3(normal, Hh), 0.0f);
-                        float NdotV = gmax(dot3(normal, viewDir), 0.0f);
-                        float cosTheta = gclamp(dot3(normal, -viewDir), 0.0f, 1.0f);
-                        v3 Fr = F0 + (1.0f - F0) * pow5(1.0f - cosTheta);
-                        float a2 = alpha * alpha;
-                        float denom = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
-                        float D = a2 / (PI * denom * denom);
-                        float k = (alpha + 1) * (alpha + 1) / 8.0f;
-                        float G_V = NdotV / (NdotV * (1.0f - k) + k);
-                        float G_L = NdotL / (NdotL * (1.0f - k) + k);
-                        float G = G_V * G_L;
-                        v3 specular = (D * Fr * G) / (4.0f * NdotV * NdotL + 0.001f);
-                        v3 diffuse = diffuseColor / PI;
-                        v3 radiance = mk(L2.x, L2.y, L2.z) * attenuation;
-                        v3 contrib = (diffuse + specular) * radiance * NdotL * strength;
-                        // A contribution of exactly +-0 in all three channels (mirror metals: diffuse 0 and D = 0) leaves
-                        // the pixel sum unchanged bit for bit whether or not it is added (the sum starts at +0 and
-                        // x + (+-0) == x), so the shadow ray that would decide it is not traced.  NaN fails the test.
-                        const bool nothing = cast && contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f;
-                        if (nothing) skipped++;
-                        else {
-                            pendOut = make_float4(contrib.x, contrib.y, contrib.z, cast ? 1.f : 2.f);
-                            if (cast) { wantShadow = true; pending++; }
-                        }
-                        // cast == false: a light type the shader does not know gets no shadow test and its
-                        // contribution (only reachable with a NaN normal) is added directly: w = 2
-                    } else if (cast) skipped++;
-                    logp[(size_t)l * P.nslots] = pendOut;
-                }
-
-                // shader.comp:524-530
-                if (transmission == 0.f)
-                    strength = strength * mk(gclamp(baseColor.x, 0.f, 1.f), gclamp(baseColor.y, 0.f, 1.f), gclamp(baseColor.z, 0.f, 1.f));
-                bool active = !(length3(strength) < F.strengthCutoff);
-                cont = active && (bounce + 1 < F.maxBounces);
+            const v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122); only used for hits
+            const ShadeResult R = shade_path<TEX, GLASS, MANY, SUN1>(S, F, P, bounce, px, py, r, slot, h2, rayLoc, rayDir, strength, refracting, hitLoc,
+                                                                     imgAlbedo, imgNormal, imgDepth, primTri, primHit);
+            rayLoc = R.o; rayDir = R.d; strength = R.s; refracting = R.refracting; cont = R.cont; wantShadow = R.wantShadow;
+            pending += R.pending; skipped += R.skipped;
+            if (ref >= 0) {
                 if (cont || wantShadow) {
                     const uint32_t st = (uint32_t)item * RT_BLOCK + threadIdx.x;
                     stageA[st] = make_float4(rayLoc.x, rayLoc.y, rayLoc.z, rayDir.x);

@@ -94,13 +94,27 @@ __device__ __forceinline__ void slab_pair_s(v3 o, v3 inv, float4 n0, float4 n1, 
 // (measured 16/12, 32/8, 48/4: 32/8 best on C2..C5).
 #define RT_TRI_MIN 32
 #define RT_NODE_LOW 8
+// Scheduling knobs of the refill kernels, packed into one kernel argument (scalar registers, no VGPR):
+//   bits 0..7 nodeMin, 8..15 triMin (0 = RT_TRI_MIN), 16..23 nodeLow (0 = RT_NODE_LOW), bit 24 defer: when the node phase
+//   ends only because finished lanes can be refilled, the parked leaves wait (the refill comes first and the triangle phase
+//   runs later with more lanes)
+struct RefillSched { int nodeMin, triMin, nodeLow; bool defer; };
+__device__ __forceinline__ RefillSched unpack_sched(int v) {
+    RefillSched r;
+    r.nodeMin = v & 255; r.triMin = (v >> 8) & 255; r.nodeLow = (v >> 16) & 255; r.defer = ((v >> 24) & 1) != 0;
+    if (r.triMin == 0) r.triMin = RT_TRI_MIN;
+    if (r.nodeLow == 0) r.nodeLow = RT_NODE_LOW;
+    return r;
+}
 template <bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
                                                          const float4* __restrict__ rays, const uint32_t* __restrict__ count,
-                                                         int rBase, uint32_t rayCount, int refillIdle, int nodeMin,
+                                                         int rBase, uint32_t rayCount, int refillIdle, int schedBits,
                                                          DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
     __shared__ float poolMem[RT_BLOCK / 64][RT_POOL_WORDS][64];
+    const RefillSched sched = unpack_sched(schedBits);
+    const int nodeMin = sched.nodeMin;
     const Stack stk = make_stack(lds, P);
     float (*pool)[64] = poolMem[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
@@ -110,6 +124,8 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
     uint32_t poolN = 0;          // prepared rays waiting in the pool (wave-uniform)
     uint32_t nNodes = 0, nTris = 0, maxSteps = 0, steps0 = 0;
     uint32_t wNode = 0, wTri = 0, bNodes = 0, bTris = 0;   // COUNT: wave-level step executions and the visits made in them (as k_extend's)
+    uint32_t dbg2[4] = {0, 0, 0, 0};                       // COUNT: node / triangle steps made when no refill was possible, and their lanes
+    uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // COUNT, lane 0: node-phase exits [0], parked lanes at them [1], by reason [2..6], free lanes [7]
 
     bool active = false;
     uint32_t slot = 0;
@@ -214,19 +230,29 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
             // `pend` and goes on with the next node of its stack; with a leaf parked and another at hand it waits.  The
             // phase ends when too few lanes are left and there is something else to do (parked leaves to test, or
             // finished lanes to refill).
+            bool skipTris = false;
             for (;;) {
                 const bool hasNode = cur >= 0;
                 const int nNode = __popcll(__ballot(hasNode));
-                if (nNode == 0) break;
                 if (nNode < nodeMin) {
                     const int nParked = __popcll(__ballot(pend != RT_DONE));
                     const int nFree = __popcll(__ballot(!active || (cur == RT_DONE && pend == RT_DONE)));
-                    if (nParked >= RT_TRI_MIN || (nParked > 0 && nNode < RT_NODE_LOW) || (canRefill && nFree >= refillIdle)) break;
+                    const bool wantTris = nParked >= sched.triMin || (nParked > 0 && nNode < sched.nodeLow);
+                    const bool wantRefill = canRefill && nFree >= refillIdle;
+                    if (wantRefill && sched.defer && nParked < sched.triMin) { skipTris = true; if (COUNT && lane == 0) dbg[4]++; break; }
+                    if (nNode == 0 || wantTris || wantRefill) {
+                        if (COUNT && lane == 0) {
+                            dbg[0]++; dbg[1] += (uint32_t)nParked;
+                            if (nParked >= sched.triMin) dbg[2]++; else if (wantTris) dbg[3]++; else if (wantRefill) dbg[5]++; else dbg[6]++;
+                            dbg[7] += (uint32_t)nFree;
+                        }
+                        break;
+                    }
                 }
                 if (hasNode) {
                     const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
                     float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                    if (COUNT) { nNodes++; bNodes++; if (first_active_lane()) wNode++; }
+                    if (COUNT) { nNodes++; bNodes++; if (first_active_lane()) { wNode++; if (!canRefill) { dbg2[0]++; dbg2[1] += (uint32_t)nNode; } } }
                     float te0, tx0, te1, tx1;
                     slab_pair_s(o, rinv, n0, n1, n2, te0, tx0, te1, tx1);
                     bool p0 = tx0 >= te0 && tx0 >= 0.0f && !(te0 > lim);
@@ -246,12 +272,12 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
             // Triangle phase: every lane with a parked leaf tests it; a second leaf waiting in `cur` is parked next.
             // (One triangle per phase instead of the whole leaf, so that a phase is as short as its shortest leaf, was
             // measured: 4 % slower.)
-            if (pend != RT_DONE) {
+            if (!skipTris && pend != RT_DONE) {
                 int code = -pend - 1;
                 int first = code >> 3, cnt = code & 7;
                 const float4* tp = reinterpret_cast<const float4*>(S.tris + first);
                 for (int k = 0; k < cnt; k++) {
-                    if (COUNT) { nTris++; bTris++; if (first_active_lane()) wTri++; }
+                    if (COUNT) { nTris++; bTris++; if (first_active_lane()) { wTri++; if (!canRefill) { dbg2[2]++; dbg2[3] += (uint32_t)__popcll(__ballot(true)); } } }
                     float4 A = tp[3 * k], B = tp[3 * k + 1], C = tp[3 * k + 2];
                     float t;
                     if (tri_t(A, B, C, o, d, &t)) {
@@ -291,7 +317,10 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
             wNode += __shfl_down(wNode, off, 64); wTri += __shfl_down(wTri, off, 64);
         }
         for (int off = 32; off > 0; off >>= 1) { uint32_t o2 = __shfl_down(maxSteps, off, 64); if (o2 > maxSteps) maxSteps = o2; }
+        for (int k = 0; k < 4; k++) if (dbg2[k]) atomicAdd(&stats->dbg2[k], (unsigned long long)dbg2[k]);
         if ((threadIdx.x & 63) == 0) {
+            for (int k = 0; k < 8; k++) if (dbg[k]) atomicAdd(&stats->dbg[k], (unsigned long long)dbg[k]);
+
             atomicAdd(&red[0], nNodes); atomicAdd(&red[1], nTris); atomicAdd(&red[2], bNodes); atomicAdd(&red[3], bTris);
             atomicAdd(&red[4], wNode); atomicAdd(&red[5], wTri);
             if (maxSteps) atomicMax(&stats->max_ray_steps, (unsigned long long)maxSteps);
@@ -316,9 +345,11 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
 // what a miss-latency-bound kernel wants) and the direction's reciprocal is computed once per thread.
 template <bool COUNT, bool SUN1>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
-                                                         int bounce, int refillIdle, int nodeMin, DeviceStats* stats) {
+                                                         int bounce, int refillIdle, int schedBits, DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
     const Stack stk = make_stack(lds, P);
+    const RefillSched sched = unpack_sched(schedBits);
+    const int nodeMin = sched.nodeMin;
     const uint32_t L = (uint32_t)F.numLights;
     const uint32_t n = *count * L;
     const float INF = __int_as_float(0x7f800000);
@@ -423,14 +454,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
 
         for (;;) {
             // node phase / triangle phase with parked leaves, as in k_extend_refill
+            bool skipTris = false;
             for (;;) {
                 const bool hasNode = cur >= 0;
                 const int nNode = __popcll(__ballot(hasNode));
-                if (nNode == 0) break;
                 if (nNode < nodeMin) {
                     const int nParked = __popcll(__ballot(pend != RT_DONE));
                     const int nFree = __popcll(__ballot(!active || (cur == RT_DONE && pend == RT_DONE)));
-                    if (nParked >= RT_TRI_MIN || (nParked > 0 && nNode < RT_NODE_LOW) || (canRefill && nFree >= refillIdle)) break;
+                    const bool wantTris = nParked >= sched.triMin || (nParked > 0 && nNode < sched.nodeLow);
+                    const bool wantRefill = canRefill && nFree >= refillIdle;
+                    if (wantRefill && sched.defer && nParked < sched.triMin) { skipTris = true; break; }
+                    if (nNode == 0 || wantTris || wantRefill) break;
                 }
                 if (hasNode) {
                     const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
@@ -451,7 +485,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
                     if (cur < 0 && cur != RT_DONE && pend == RT_DONE) { pend = cur; popS(); }
                 }
             }
-            if (pend != RT_DONE) {
+            if (!skipTris && pend != RT_DONE) {
                 int code = -pend - 1;
                 int first = code >> 3, cnt = code & 7;
                 const float4* tp = reinterpret_cast<const float4*>(S.tris + first);

@@ -153,6 +153,8 @@ struct DeviceStats {
     unsigned long long max_ray_steps;                          // most node visits + triangle tests by one closest-hit ray
     unsigned long long bounce_node_visits, bounce_tri_tests;   // closest-hit traversal of bounces >= 1 only
     unsigned long long wave_node_steps, wave_tri_steps;        // wave-level executions of the node / triangle step there
+    unsigned long long dbg2[4];
+    unsigned long long dbg[8];                                 // instrumented refill kernel: scheduling census (RT_DEBUG=1 prints it)
 };
 
 }  // namespace rt

@@ -150,7 +150,8 @@ def test_million_random_rays_both_modes(scenes):
 
 @pytest.mark.parametrize("knobs", [{}, {"refill": 1}, {"refill": 1, "refillIdle": 1, "refillBlocksPerCU": 1}, {"traversalMode": 1},
                                    {"refill": 1, "refillNodeMin": 1}, {"refill": 1, "refillNodeMin": 64, "refillIdle": 64},
-                                   {"refill": 1, "refillNodeMin": 64, "refillIdle": 1, "passStreams": 1}])
+                                   {"refill": 1, "refillNodeMin": 64, "refillIdle": 1, "passStreams": 1},
+                                   {"refill": 1, "refillDefer": 1, "refillTriMin": 8, "refillNodeLow": 2}])
 def test_synthetic_height_field_bit_exact(oracle_lib, tmp_path, knobs):
     """Config 4's generator at a size the oracle finishes in seconds (2 x 150^2 = 45 000 triangles, tree depth > the
     8 LDS stack entries, centroid ties): the same GLTF through the product's loader/builder/kernels and through the
