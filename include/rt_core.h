@@ -80,7 +80,8 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * traversal waves that hand finished lanes new rays; automatic = the first four sizeable frames after a scene upload
  * are rendered with the four combinations (refill or not, for closest-hit and for shadow rays) and the fastest is kept;
  * until then BVHs far larger than the L2s use them and others do not), kernelChoice (-1 / 0..3: that combination whatever
- * was measured, reported back in rt_stats.kernel_choice; a multi-GPU job gives every rank rank 0's), refillIdle, refillNodeMin,
+ * was measured, reported back in rt_stats.kernel_choice; a multi-GPU job gives every rank rank 0's), fusePairs (1 / 0: the
+ * shadow rays of a bounce and the closest-hit rays of the next are traced by one launch), refillIdle, refillNodeMin,
  * refillBlocksPerCU. */
 rt_status rt_set_int(rt_ctx* ctx, const char* name, int32_t v);
 rt_status rt_set_float(rt_ctx* ctx, const char* name, float v);
@@ -155,6 +156,8 @@ typedef struct rt_stats {
     int32_t  kernel_choice;    /* traversal kernels this call ran: bit 0 = refill kernel for closest-hit rays of bounces >= 1,
                                   bit 1 = for shadow rays; -2 = reference-order walk (traversalMode 1 or forced) */
     int32_t  kernel_choice_settled;  /* 1: fixed by a knob or by the finished per-scene trial; 0: a trial frame or the default */
+    uint64_t launches_pair;    /* launches that traced the shadow rays of a bounce and the closest-hit rays of the next together
+                                  (k_trace_pair, knob fusePairs); they are counted and timed under launches_extend / ms_extend */
 } rt_stats;
 rt_status rt_get_stats(rt_ctx* ctx, rt_stats* out);
 

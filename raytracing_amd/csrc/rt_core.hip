@@ -81,7 +81,7 @@ struct rt_ctx {
     DevBuf accum, dStats;
     hipStream_t extra[kMaxSets] = {};     // streams of sets 1.. (set 0 uses `stream`)
     hipEvent_t evResolve[kMaxSets] = {}, evInit = nullptr;
-    int32_t passStreams = 4, autoPass = 1;
+    int32_t passStreams = 4, autoPass = 1, fusePairs = 1;
     // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill 0 = never, 1 = always, -1 = chosen per scene.
     int32_t refill = -1, refillIdle = 16, refillNodeMin = 28, refillBlocksPerCU = 0;
     int32_t refillTriMin = 0, refillNodeLow = 0, refillDefer = 0;   // 0 = the kernels' defaults (rt_trace_refill.hip.h, RefillSched)   // refillBlocksPerCU 0 = automatic (refill_blocks)
@@ -346,7 +346,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     {
         const uint64_t bytesPerSlot = 2 * 32 + 2 * 16 + 8 + 16 + 16 + 4 + 16ull * (uint64_t)std::max(1, F.numLights) * std::max<uint32_t>(1, maxB);
         const uint64_t wantSets = (uint64_t)std::min<int>(std::max(1, (int)c->passStreams), rt_ctx::kMaxSets);
-        uint64_t slotBudget = std::min<uint64_t>(1ull << 28, (c->deviceBytes / 2) / (wantSets * bytesPerSlot));
+        uint64_t slotBudget = std::min<uint64_t>(1ull << 30, (c->deviceBytes / 2) / (wantSets * bytesPerSlot));
         if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
     }
     if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
@@ -452,6 +452,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     };
     auto evEnd = [&](rt_ctx::EvPair* e) { if (e) (void)hipEventRecord(e->b, st); };
     uint32_t passNo = 0;
+    uint64_t nPairs = 0;
 
     for (uint32_t rBase = r0; rBase < r1; rBase += S_) {
         const uint32_t inPass = std::min(S_, r1 - rBase);
@@ -467,21 +468,29 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         const uint32_t tb = std::min(traceBlocks, passBlocks);
         HIPCHK(c, hipMemsetAsync(P.counters, 0, (size_t)(2 * (maxB + 1)) * 4, st));
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)qcount, (int)Pp.nslots, 1, st));   // bounce 0: every slot carries a path
+        const bool sun1 = F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel;
+        // Shadow rays of bounce b and closest-hit rays of bounce b + 1 both come out of k_shade(b) and do not depend on
+        // each other: they are traced by one launch (k_trace_pair), which costs the slower of the two instead of their sum.
+        const bool pairs = !exact && !count && c->fusePairs != 0 && F.numLights > 0;
+        bool extendDone = false;
         for (uint32_t b = 0; b < maxB; b++) {
             const float4* qin = b == 0 ? nullptr : P.ray[b & 1];       // bounce 0: entry i is slot i, camera rays are regenerated
-            rt_ctx::EvPair* e = evBegin(b == 0 ? 3 : 0);
-            if (refillExtend && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
-                const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
-                if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
-                else k_extend_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
+            rt_ctx::EvPair* e = nullptr;
+            if (!extendDone) {
+                e = evBegin(b == 0 ? 3 : 0);
+                if (refillExtend && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
+                    const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
+                    if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
+                    else k_extend_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
+                }
+                else if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const float4*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
+                else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
+                evEnd(e);
             }
-            else if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const float4*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
-            else launch_extend<false>(exact, count, dim3(tb), st, S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, dst);
-            evEnd(e);
+            extendDone = false;
             e = evBegin(1);
             {
                 const bool many = F.numLights > RT_MAX_LIGHTS;
-                const bool sun1 = F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel;
                 auto shadeK = c->anyTextured ? (many ? k_shade<true, true, true, false> : k_shade<true, true, false, false>)
                             : c->anyTransmissive ? (many ? k_shade<false, true, true, false> : sun1 ? k_shade<false, true, false, true> : k_shade<false, true, false, false>)
                                                  : (many ? k_shade<false, false, true, false> : sun1 ? k_shade<false, false, false, true> : k_shade<false, false, false, false>);
@@ -490,15 +499,32 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             }
             evEnd(e);
             if (F.numLights > 0) {
+                if (pairs && b + 1 < maxB) {
+                    const uint32_t rg = refill_blocks(c, Pp.nslots, nSets);
+                    const uint32_t gE = refillExtend ? rg : tb, gS = refillShadow ? rg : tb;
+                    const dim3 g(std::max(gE, gS));
+                    const float4* qnext = P.ray[(b + 1) & 1];
+                    const uint32_t* cE = qcount + b + 1;
+                    const uint32_t* cS = scount + b;
+                    const int shd = refillShadow ? (sun1 ? 3 : 2) : (sun1 ? 1 : 0);
+                    e = evBegin(0);
+#define RT_PAIR(EXT, SHD) k_trace_pair<EXT, SHD><<<g, RT_BLOCK, 0, st>>>(S, F, Pp, qnext, cE, (int)rBase, cS, (int)b, gE, gS, refillIdle, refillNodeMin, dst)
+                    if (refillExtend) { if (shd == 0) RT_PAIR(1, 0); else if (shd == 1) RT_PAIR(1, 1); else if (shd == 2) RT_PAIR(1, 2); else RT_PAIR(1, 3); }
+                    else { if (shd == 0) RT_PAIR(0, 0); else if (shd == 1) RT_PAIR(0, 1); else if (shd == 2) RT_PAIR(0, 2); else RT_PAIR(0, 3); }
+#undef RT_PAIR
+                    evEnd(e);
+                    nPairs++;
+                    extendDone = true;
+                    continue;
+                }
                 e = evBegin(2);
                 if (refillShadow) {
                     const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
-                    const bool sun1r = F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel;
                     if (count) k_shadow_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
-                    else if (sun1r) k_shadow_refill<false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
+                    else if (sun1) k_shadow_refill<false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
                     else k_shadow_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
                 }
-                else if (!exact && !count && F.numLights == 1 && F.lights[0].lightType == 1u && c->sunKernel)
+                else if (!exact && !count && sun1)
                     k_shadow_sun<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b);
                 else launch_shadow(exact, count, dim3(tb), st, S, F, Pp, (const uint32_t*)(scount + b), (int)b, dst);
                 evEnd(e);
@@ -559,6 +585,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.ms_extend = msAcc[0] + msAcc[3]; c->stats.ms_shade = msAcc[1]; c->stats.ms_shadow = msAcc[2];
     c->stats.launches_extend = nLaunch[0] + nLaunch[3]; c->stats.launches_shade = nLaunch[1]; c->stats.launches_shadow = nLaunch[2];
     c->stats.ms_extend_primary = msAcc[3]; c->stats.launches_extend_primary = nLaunch[3];
+    c->stats.launches_pair = nPairs;
     c->stats.kernel_choice = exact ? -2 : combo;
     c->stats.kernel_choice_settled = (exact || c->refill >= 0 || c->kernelChoice >= 0 || c->tuneState >= 4) ? 1 : 0;
     c->primValid = aov;
@@ -701,6 +728,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "kernelChoice")) c->kernelChoice = v < 0 ? -1 : (v & 3);
     else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 0 ? 0 : v;
     else if (name_is(name, "autoPass")) c->autoPass = v;
+    else if (name_is(name, "fusePairs")) c->fusePairs = v;
     else if (name_is(name, "passStreams")) c->passStreams = v < 1 ? 4 : v;      // < 1: back to the default
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
 }

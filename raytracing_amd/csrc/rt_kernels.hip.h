@@ -443,16 +443,18 @@ __device__ __forceinline__ bool primary_ray(const FrameParams& F, const PathBuff
 
 // rays: the bounce's ray buffer (PRIMARY: unused, entry i is slot i).  rayCount > 0 overrides the number of rays added to the counters
 // (bounce 0: region pixels, not slots).
+// The traversal kernels below are written as bodies (…_batch, …_refill) that take their block index and grid size as
+// arguments, with a __global__ wrapper each: k_trace_pair runs two of them in one launch (rt_trace_refill.hip.h).
+// lds: RT_LDS_STACK x RT_BLOCK stack entries of the workgroup.
 template <bool EXACT, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F, PathBuffers P, const float4* __restrict__ rays,
-                                                     const uint32_t* __restrict__ count, int rBase, uint32_t rayCount,
-                                                     DeviceStats* stats) {
-    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+__device__ __forceinline__ void extend_batch(const SceneView& S, const FrameParams& F, const PathBuffers& P, const float4* __restrict__ rays,
+                                             const uint32_t* __restrict__ count, int rBase, uint32_t rayCount,
+                                             DeviceStats* stats, uint2* lds, uint32_t bid, uint32_t nblk) {
     const Stack stk = make_stack(lds, P);
     uint32_t n = *count;
     uint32_t nNodes = 0, nTris = 0, maxSteps = 0;
     uint32_t wSteps[2] = {0u, 0u};
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+    for (uint32_t i = bid * RT_BLOCK + threadIdx.x; i < n; i += nblk * RT_BLOCK) {
         v3 ro, rd;
         if (PRIMARY) {
             int px, py, r;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F,
         if (COUNT) { uint32_t steps = nNodes + nTris - before; if (steps > maxSteps) maxSteps = steps; }
         P.hit[i] = make_float2(best.t, __int_as_float(best.ref));
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    if (bid == 0 && threadIdx.x == 0)
         atomicAdd(PRIMARY ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)(rayCount ? rayCount : n));
     if (COUNT) {
         __shared__ uint32_t red[4];
@@ -496,6 +498,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F,
             }
         }
     }
+}
+
+template <bool EXACT, bool COUNT, bool PRIMARY>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(SceneView S, FrameParams F, PathBuffers P, const float4* __restrict__ rays,
+                                                     const uint32_t* __restrict__ count, int rBase, uint32_t rayCount,
+                                                     DeviceStats* stats) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    extend_batch<EXACT, COUNT, PRIMARY>(S, F, P, rays, count, rBase, rayCount, stats, lds, blockIdx.x, gridDim.x);
 }
 
 // texture(sampler2D(handle), uv): LINEAR, REPEAT, level 0, RGBA8 unorm (Texture.cpp:5-34; GL 4.3 8.14).
@@ -892,9 +902,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(SceneView S,
 // thread instead of once per ray (three IEEE divisions), every queued entry awaits its ray (no flag to read), and none
 // of the point-light state (shade location, distance to the light, distance limit) is carried: 64 instead of 75
 // registers, i.e. 8 instead of 6 waves per SIMD.  Same arithmetic per ray as occluded_fast<.., true> with kind = 1.
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow_sun(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
-                                                         int bounce) {
-    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+__device__ __forceinline__ void shadow_sun_batch(const SceneView& S, const FrameParams& F, const PathBuffers& P, const uint32_t* __restrict__ count,
+                                                 int bounce, uint2* lds, uint32_t bid, uint32_t nblk) {
     const Stack stk = make_stack(lds, P);
     const uint32_t n = *count;
     const RefLight Lg = F.lights[0];
@@ -903,7 +912,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_sun(SceneView S, FrameParam
     const float big = 3.0e38f;
     const bool dPlain = fabsf(d.x) < big && fabsf(d.y) < big && fabsf(d.z) < big && d.x != 0.f && d.y != 0.f && d.z != 0.f;
     float4* const logBase = P.contrib + (size_t)bounce * P.lightSlots * P.nslots;
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+    for (uint32_t i = bid * RT_BLOCK + threadIdx.x; i < n; i += nblk * RT_BLOCK) {
         const float4 o4 = P.shadowRec[i];
         const uint32_t slot = __float_as_uint(o4.w);
         const v3 o = mk(o4.x, o4.y, o4.z);
@@ -956,15 +965,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_sun(SceneView S, FrameParam
     }
 }
 
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow_sun(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
+                                                         int bounce) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    shadow_sun_batch(S, F, P, count, bounce, lds, blockIdx.x, gridDim.x);
+}
+
 // shader.comp:453-484: the shadow lineCast of every log entry awaiting one; the entry becomes "add" (2) or "none" (0).
 template <bool EXACT, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
-                                                     int bounce, DeviceStats* stats) {
-    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+__device__ __forceinline__ void shadow_batch(const SceneView& S, const FrameParams& F, const PathBuffers& P, const uint32_t* __restrict__ count,
+                                             int bounce, DeviceStats* stats, uint2* lds, uint32_t bid, uint32_t nblk) {
     const Stack stk = make_stack(lds, P);
     uint32_t n = *count;
     uint32_t nNodes = 0, nTris = 0;
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+    for (uint32_t i = bid * RT_BLOCK + threadIdx.x; i < n; i += nblk * RT_BLOCK) {
         const float4 o4 = P.shadowRec[i];
         const uint32_t slot = __float_as_uint(o4.w);
         v3 o = mk(o4.x, o4.y, o4.z), hitLoc = mk(0.f, 0.f, 0.f);
@@ -1009,6 +1023,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
             atomicAdd(&stats->shadow_tri_tests, (unsigned long long)red[1]);
         }
     }
+}
+
+template <bool EXACT, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
+                                                     int bounce, DeviceStats* stats) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    shadow_batch<EXACT, COUNT>(S, F, P, count, bounce, stats, lds, blockIdx.x, gridDim.x);
 }
 
 // shader.comp:332 and 521: `color.rgb += ...` replayed per pixel in the shader's own order — samples ascending,

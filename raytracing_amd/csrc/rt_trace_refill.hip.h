@@ -55,11 +55,12 @@ struct WavePool {
         if (next >= end && group < n) { group = (n - group <= stride) ? n : group + stride; open_group(); }
     }
 };
-__device__ __forceinline__ WavePool wave_pool(uint32_t n) {
+// bid / nblk: this workgroup's index in, and the size of, the (virtual) grid that shares the n items.
+__device__ __forceinline__ WavePool wave_pool(uint32_t n, uint32_t bid, uint32_t nblk) {
     WavePool wp;
     wp.n = n;
-    wp.stride = gridDim.x * RT_BLOCK;
-    wp.group = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * 64u));
+    wp.stride = nblk * RT_BLOCK;
+    wp.group = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * 64u));
     wp.open_group();
     return wp;
 }
@@ -106,13 +107,12 @@ __device__ __forceinline__ RefillSched unpack_sched(int v) {
     if (r.nodeLow == 0) r.nodeLow = RT_NODE_LOW;
     return r;
 }
+typedef float RayPool[RT_POOL_WORDS][64];      // one wave's pool of prepared rays
 template <bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
-                                                         const float4* __restrict__ rays, const uint32_t* __restrict__ count,
-                                                         int rBase, uint32_t rayCount, int refillIdle, int schedBits,
-                                                         DeviceStats* stats) {
-    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
-    __shared__ float poolMem[RT_BLOCK / 64][RT_POOL_WORDS][64];
+__device__ __forceinline__ void extend_refill(const SceneView& S, const FrameParams& F, const PathBuffers& P,
+                                              const float4* __restrict__ rays, const uint32_t* __restrict__ count,
+                                              int rBase, uint32_t rayCount, int refillIdle, int schedBits,
+                                              DeviceStats* stats, uint2* lds, RayPool* poolMem, uint32_t bid, uint32_t nblk) {
     const RefillSched sched = unpack_sched(schedBits);
     const int nodeMin = sched.nodeMin;
     const Stack stk = make_stack(lds, P);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = *count;
     const float INF = __int_as_float(0x7f800000);
-    WavePool wp = wave_pool(n);
+    WavePool wp = wave_pool(n, bid, nblk);
     uint32_t poolN = 0;          // prepared rays waiting in the pool (wave-uniform)
     uint32_t nNodes = 0, nTris = 0, maxSteps = 0, steps0 = 0;
     uint32_t wNode = 0, wTri = 0, bNodes = 0, bTris = 0;   // COUNT: wave-level step executions and the visits made in them (as k_extend's)
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
         }
     }
 
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    if (bid == 0 && threadIdx.x == 0)
         atomicAdd(PRIMARY ? &stats->rays_primary : &stats->rays_bounce, (unsigned long long)(rayCount ? rayCount : n));
     if (COUNT) {
         __shared__ uint32_t red[6];
@@ -339,21 +339,30 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, Fram
     }
 }
 
+template <bool COUNT, bool PRIMARY>
+__global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
+                                                         const float4* __restrict__ rays, const uint32_t* __restrict__ count,
+                                                         int rBase, uint32_t rayCount, int refillIdle, int schedBits,
+                                                         DeviceStats* stats) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    __shared__ RayPool poolMem[RT_BLOCK / 64];
+    extend_refill<COUNT, PRIMARY>(S, F, P, rays, count, rBase, rayCount, refillIdle, schedBits, stats, lds, poolMem, blockIdx.x, gridDim.x);
+}
+
 // shader.comp:453-484: the shadow lineCast of every log entry awaiting one; the entry becomes "add" (2) or "none" (0).
 // Work item i = (shadow-queue entry i / numLights, light i % numLights).
 // SUN1: exactly one light and it is a sun — no point-light state is carried (fewer registers, more resident waves, which is
 // what a miss-latency-bound kernel wants) and the direction's reciprocal is computed once per thread.
 template <bool COUNT, bool SUN1>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
-                                                         int bounce, int refillIdle, int schedBits, DeviceStats* stats) {
-    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+__device__ __forceinline__ void shadow_refill(const SceneView& S, const FrameParams& F, const PathBuffers& P, const uint32_t* __restrict__ count,
+                                              int bounce, int refillIdle, int schedBits, DeviceStats* stats, uint2* lds, uint32_t bid, uint32_t nblk) {
     const Stack stk = make_stack(lds, P);
     const RefillSched sched = unpack_sched(schedBits);
     const int nodeMin = sched.nodeMin;
     const uint32_t L = (uint32_t)F.numLights;
     const uint32_t n = *count * L;
     const float INF = __int_as_float(0x7f800000);
-    WavePool wp = wave_pool(n);
+    WavePool wp = wave_pool(n, bid, nblk);
     uint32_t nNodes = 0, nTris = 0;
 
     bool active = false, occ = false;
@@ -522,6 +531,42 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
             atomicAdd(&stats->shadow_node_visits, (unsigned long long)red[0]);
             atomicAdd(&stats->shadow_tri_tests, (unsigned long long)red[1]);
         }
+    }
+}
+
+template <bool COUNT, bool SUN1>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
+                                                         int bounce, int refillIdle, int schedBits, DeviceStats* stats) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    shadow_refill<COUNT, SUN1>(S, F, P, count, bounce, refillIdle, schedBits, stats, lds, blockIdx.x, gridDim.x);
+}
+
+// The shadow rays of bounce b and the closest-hit rays of bounce b + 1 in ONE launch.  Both queues are written by
+// k_shade of bounce b and neither kernel reads what the other writes, yet on a stream they ran one after the other — and
+// late bounces are short queues of long rays (scene 7: 75 k .. 800 k rays from bounce 4 on, up to ~750 traversal steps
+// each), whose launches last as long as their slowest ray with the chip almost idle.  Run together, a bounce costs the
+// slower of the two instead of their sum, and on large queues a wave that has finished its share of one kind goes
+// straight on with the other instead of idling through the first kernel's drain.
+// Workgroup b of the launch runs the closest-hit body as workgroup b of a grid of gE, then the shadow body as workgroup
+// (gridDim - 1 - b) of a grid of gS: short queues therefore land on opposite ends of the launch and run side by side.
+// EXT: 0 extend_batch, 1 extend_refill.  SHD: 0 shadow_batch, 1 shadow_sun_batch, 2 shadow_refill<., false>, 3 shadow_refill<., true>.
+template <int EXT, int SHD>
+__global__ __launch_bounds__(RT_BLOCK, ((EXT == 1 && SHD != 2) ? 6 : 1)) void k_trace_pair(SceneView S, FrameParams F, PathBuffers P,
+                                                                          const float4* __restrict__ rays, const uint32_t* __restrict__ countExt,
+                                                                          int rBase, const uint32_t* __restrict__ countShd, int bounceShd,
+                                                                          uint32_t gE, uint32_t gS, int refillIdle, int schedBits, DeviceStats* stats) {
+    __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
+    __shared__ RayPool poolMem[EXT == 1 ? RT_BLOCK / 64 : 1];
+    if (blockIdx.x < gE) {
+        if (EXT == 1) extend_refill<false, false>(S, F, P, rays, countExt, rBase, 0u, refillIdle, schedBits, stats, lds, poolMem, blockIdx.x, gE);
+        else extend_batch<false, false, false>(S, F, P, rays, countExt, rBase, 0u, stats, lds, blockIdx.x, gE);
+    }
+    const uint32_t bs = gridDim.x - 1u - blockIdx.x;
+    if (bs < gS) {
+        if (SHD == 0) shadow_batch<false, false>(S, F, P, countShd, bounceShd, stats, lds, bs, gS);
+        else if (SHD == 1) shadow_sun_batch(S, F, P, countShd, bounceShd, lds, bs, gS);
+        else if (SHD == 2) shadow_refill<false, false>(S, F, P, countShd, bounceShd, refillIdle, schedBits, stats, lds, bs, gS);
+        else shadow_refill<false, true>(S, F, P, countShd, bounceShd, refillIdle, schedBits, stats, lds, bs, gS);
     }
 }
 

@@ -16,7 +16,11 @@ VEC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vector
 # dynamic-fetch traversal kernels, one sample per pass on three overlapping streams, a single stream
 VARIANTS = {"culled": {"traversalMode": 0}, "reference_order": {"traversalMode": 1},
             "dynamic_fetch": {"refill": 1, "refillIdle": 24}, "dynamic_fetch_eager": {"refill": 1, "refillIdle": 1},
-            "streams3_spp1": {"samplesPerPass": 1, "passStreams": 3}, "one_stream": {"samplesPerPass": 2, "passStreams": 1}}
+            "streams3_spp1": {"samplesPerPass": 1, "passStreams": 3}, "one_stream": {"samplesPerPass": 2, "passStreams": 1},
+            # shadow rays of a bounce and closest-hit rays of the next in separate launches (the default traces them together),
+            # and every pairing of batch / refill kernels in the joint launch
+            "separate_launches": {"fusePairs": 0}, "pair_refill_batch": {"kernelChoice": 1}, "pair_batch_refill": {"kernelChoice": 2},
+            "pair_refill_refill": {"kernelChoice": 3, "refillBlocksPerCU": 2, "blocksPerCU": 3}}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
