@@ -314,7 +314,7 @@ std::vector<GPUBoundingBox> Model::BVH() {
         materialOffset += (uint32_t)materialData.size();
     }
     auto t1 = std::chrono::steady_clock::now();
-    std::vector<GPUBoundingBox> BVHList = build_bvh(triangles.data(), triangles.size());
+    std::vector<GPUBoundingBox> BVHList = build_bvh(triangles.data(), triangles.size(), 0, /*allowGpu=*/!g_dry);   // a dry run (no context) stays on the host
     auto t2 = std::chrono::steady_clock::now();
     SSBO::Bind(verticesList.data(), (uint32_t)(verticesList.size() * sizeof(Vertex)), 0);
     SSBO::Bind(meshMatrices.data(), (uint32_t)(meshMatrices.size() * sizeof(mat4)), 1);

@@ -13,6 +13,7 @@
 #include "../../include/rt_core.h"
 #include "rt_compact.h"
 #include "rt_kernels.hip.h"
+#include "rt_bvh_sweep.hip.h"
 
 using namespace rt;
 
