@@ -240,8 +240,10 @@ def main():
         overlapped_ms = agg["ms_extend"] / n_launch
         cs.setInt("timeKernels", 1)
         cs.setInt("passStreams", 1)
+        cs.setInt("fusePairs", 0)                    # closest-hit and shadow rays in launches of their own, so that each has a duration
         cs.dispatch_region(0, 0, W, H, r0, r1)
         ex = cs.stats()
+        cs.setInt("fusePairs", next((int(kv.split("=")[1]) for kv in args.set if kv.startswith("fusePairs=")), 1))
         cs.setInt("passStreams", 0)                  # 0 = back to the library default
         cs.setInt("timeKernels", 0)
         ex_rays = ex["rays_primary"] + ex["rays_bounce"]
@@ -271,9 +273,10 @@ def main():
                   "unit": "GB/s", "traffic": traffic, "traffic_source": traffic_src,
                   "alg_bytes_per_launch": round(alg_launch, 1), "alg_rate_GBs": round(achieved, 2),
                   "compact_bvh_bytes": bvh_bytes,
-                  "timing": "exclusive: one frame with passStreams=1 after the timed region, HIP events per launch",
+                  "timing": "exclusive: one frame with passStreams=1 and fusePairs=0 after the timed region, HIP events per launch",
                   "timed_region_avg_launch_ms": round(overlapped_ms, 4),
-                  "timed_region_note": "passes overlap on 4 streams there, so a launch's duration includes co-running kernels",
+                  "timed_region_note": "passes overlap on 4 streams there and the shadow rays of a bounce share a launch with the closest-hit rays of "
+                                       "the next (k_trace_pair), so a launch's duration includes co-running work",
                   "exclusive_kernel_ms_per_frame": {k: round(ex[k], 2) for k in ("ms_extend", "ms_extend_primary", "ms_shade", "ms_shadow")},
                   "alg_bytes_per_ray": round(bytes_per_ray, 1), "avg_launch_ms": round(avg_ms, 4),
                   "launches": ex["launches_extend"], "rays_per_launch": round(ex_rays / ex_launch, 1),
