@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 #include "rt_types.h"
 
@@ -41,34 +43,57 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
                                         const RefTriangle* rtris, uint64_t nTris, CompactScene& out) {
     if (nNodes == 0) return "BVH node buffer (slot 3) is empty";
     if (nTris >= (1ull << 28)) return "too many triangles for the leaf encoding";
-    // ---- per-triangle world-space vertices + shading records ----
+    // ---- per-triangle world-space vertices + shading records (independent per triangle: spread over threads) ----
     std::vector<f3> wv(nTris * 3);
     out.shade.resize(nTris);
     out.shadeUV.resize(nTris);
-    for (uint64_t i = 0; i < nTris; i++) {
-        const RefTriangle& t = rtris[i];
-        for (int k = 0; k < 3; k++)
-            if (t.indices[k] >= nVerts) return "triangle " + std::to_string(i) + ": vertex index out of range";
-        if (t.meshIndex >= nMats) return "triangle " + std::to_string(i) + ": meshIndex out of range";
-        if (t.materialIndex >= nMaterials) return "triangle " + std::to_string(i) + ": materialIndex out of range";
-        const RefMat4& M = mats[t.meshIndex];
-        for (int k = 0; k < 3; k++) wv[i * 3 + k] = mul_point(M, verts[t.indices[k]].position, 1.f);
-        CShade& s = out.shade[i];
-        CShadeUV& su = out.shadeUV[i];
-        std::memset(&su, 0, sizeof su);
-        s.pad = 0;
-        const f3 P[3] = {t.p1, t.p2, t.p3};
-        float* dstP[3] = {s.a, s.b, s.c};
-        float* dstN[3] = {s.n1, s.n2, s.n3};
-        float* dstUV[3] = {su.uv1, su.uv2, su.uv3};
-        for (int k = 0; k < 3; k++) {
-            dstP[k][0] = P[k].x; dstP[k][1] = P[k].y; dstP[k][2] = P[k].z;
-            f3 n = mul_point(M, verts[t.indices[k]].normal, 0.f);
-            dstN[k][0] = n.x; dstN[k][1] = n.y; dstN[k][2] = n.z;
-            dstUV[k][0] = verts[t.indices[k]].texUV[0]; dstUV[k][1] = verts[t.indices[k]].texUV[1];
+    auto perTriangle = [&](uint64_t lo, uint64_t hi, std::string* err, uint64_t* errAt) {
+        for (uint64_t i = lo; i < hi; i++) {
+            const RefTriangle& t = rtris[i];
+            const char* bad = nullptr;
+            for (int k = 0; k < 3 && !bad; k++)
+                if (t.indices[k] >= nVerts) bad = ": vertex index out of range";
+            if (!bad && t.meshIndex >= nMats) bad = ": meshIndex out of range";
+            if (!bad && t.materialIndex >= nMaterials) bad = ": materialIndex out of range";
+            if (bad) { *err = "triangle " + std::to_string(i) + bad; *errAt = i; return; }
+            const RefMat4& M = mats[t.meshIndex];
+            for (int k = 0; k < 3; k++) wv[i * 3 + k] = mul_point(M, verts[t.indices[k]].position, 1.f);
+            CShade& s = out.shade[i];
+            CShadeUV& su = out.shadeUV[i];
+            std::memset(&su, 0, sizeof su);
+            s.pad = 0;
+            const f3 P[3] = {t.p1, t.p2, t.p3};
+            float* dstP[3] = {s.a, s.b, s.c};
+            float* dstN[3] = {s.n1, s.n2, s.n3};
+            float* dstUV[3] = {su.uv1, su.uv2, su.uv3};
+            for (int k = 0; k < 3; k++) {
+                dstP[k][0] = P[k].x; dstP[k][1] = P[k].y; dstP[k][2] = P[k].z;
+                f3 n = mul_point(M, verts[t.indices[k]].normal, 0.f);
+                dstN[k][0] = n.x; dstN[k][1] = n.y; dstN[k][2] = n.z;
+                dstUV[k][0] = verts[t.indices[k]].texUV[0]; dstUV[k][1] = verts[t.indices[k]].texUV[1];
+            }
+            s.materialIndex = t.materialIndex;
+            su.i1 = t.indices[0]; su.i2 = t.indices[1]; su.i3 = t.indices[2];
         }
-        s.materialIndex = t.materialIndex;
-        su.i1 = t.indices[0]; su.i2 = t.indices[1]; su.i3 = t.indices[2];
+    };
+    {
+        unsigned nThreads = 1;
+        if (nTris >= (1u << 18)) {
+            nThreads = std::thread::hardware_concurrency();
+            if (const char* e = std::getenv("OMP_NUM_THREADS")) { int v = std::atoi(e); if (v > 0 && (unsigned)v < nThreads) nThreads = (unsigned)v; }
+            nThreads = std::max(1u, std::min(nThreads, 32u));
+        }
+        std::vector<std::string> errs(nThreads);
+        std::vector<uint64_t> errAt(nThreads, ~0ull);
+        std::vector<std::thread> th;
+        const uint64_t per = (nTris + nThreads - 1) / nThreads;
+        for (unsigned k = 1; k < nThreads; k++)
+            th.emplace_back(perTriangle, std::min<uint64_t>(nTris, k * per), std::min<uint64_t>(nTris, (k + 1) * per), &errs[k], &errAt[k]);
+        perTriangle(0, std::min<uint64_t>(nTris, per), &errs[0], &errAt[0]);
+        for (auto& t : th) t.join();
+        unsigned first = nThreads;                       // the error of the lowest triangle index, as the sequential loop reports it
+        for (unsigned k = 0; k < nThreads; k++) if (!errs[k].empty() && (first == nThreads || errAt[k] < errAt[first])) first = k;
+        if (first != nThreads) return errs[first];
     }
 
     // ---- scene scale (for the slack terms of traversalMode 0) ----

@@ -531,6 +531,15 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                 evEnd(e);
             }
         }
+        // a launch that was refused (bad configuration, out of resources) is reported with its pass, not at the frame's end
+        {
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) {
+                for (int k = 0; k < nSets; k++) (void)hipStreamSynchronize(streams[k]);
+                return fail(c, RT_ERR_HIP, "kernel launch failed in pass " + std::to_string(passNo) + " (samples from " + std::to_string(rBase) +
+                                           ", " + std::to_string(maxB) + " bounces of k_extend / k_shade / k_shadow): " + hipGetErrorString(le));
+            }
+        }
         // the pixel sum runs over samples in order (shader.comp:312): this pass's replay follows the previous pass's
         if (nSets > 1 && passNo > 0) HIPCHK(c, hipStreamWaitEvent(st, c->evResolve[(ks + nSets - 1) % nSets], 0));
         // (maxBounces == 0: nothing was shaded, so the per-slot depths k_resolve reads were never written)
@@ -540,7 +549,11 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     }
     k_finalize<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, (float4*)c->img[0].p, aov ? 1.f : 0.f);     // on the last pass's stream, after its replay
     HIPCHK(c, hipGetLastError());
-    for (int k = 0; k < nSets; k++) HIPCHK(c, hipStreamSynchronize(streams[k]));
+    for (int k = 0; k < nSets; k++) {
+        const hipError_t se = hipStreamSynchronize(streams[k]);
+        if (se != hipSuccess)      // a fault inside a kernel surfaces here: say which stream's passes (k, k + nSets, ...) it was in
+            return fail(c, RT_ERR_HIP, "a kernel of the passes on stream " + std::to_string(k) + " of " + std::to_string(nSets) + " failed: " + hipGetErrorString(se));
+    }
     if (timeKernels) for (auto& e : c->evRing) evDrain(e);
 
     DeviceStats hs;

@@ -16,10 +16,13 @@ for r in rows[2:]:
     d = dict(zip(hdr, r))
     name = d["kernel"]
     cls = "k_extend" if "k_extend" in name else "k_shadow" if "k_shadow" in name else name.replace("rt::", "")
+    fetch, write = float(d["FETCH_SIZE"]), float(d["WRITE_SIZE"])
+    if fetch != fetch or write != write:      # a kernel that only one of the two counter passes launched (the per-scene kernel
+        continue                              # trial can settle differently from run to run): no pair of figures, skipped
     a = agg.setdefault(cls, {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
     a["launches"] += int(d["dispatches"])
-    a["fetch_kib"] += float(d["FETCH_SIZE"])
-    a["write_kib"] += float(d["WRITE_SIZE"])
+    a["fetch_kib"] += fetch
+    a["write_kib"] += write
 for cls, a in agg.items():
     if a["launches"]:
         a["hbm_bytes_per_launch"] = round((2.0 * a["fetch_kib"] + a["write_kib"]) * 1024.0 / a["launches"], 1)
