@@ -18,6 +18,7 @@ namespace rt {
 
 struct CompactScene {
     std::vector<CNode> nodes;
+    std::vector<WNode> wnodes;      // two-level view of `nodes` (empty when the tree does not allow it, see derive_wide)
     std::vector<CTri> tris;
     std::vector<CShade> shade;
     std::vector<CShadeUV> shadeUV;
@@ -26,6 +27,7 @@ struct CompactScene {
     float sceneScale = 1.f;
     bool boxesContainTris = true;   // false -> only traversalMode 1 is valid (mesh-local boxes vs world triangles)
     uint32_t maxDepth = 0;
+    uint32_t wideDepth = 0;         // levels of wide nodes on the longest root-to-leaf path
 };
 
 // vec3(M * vec4(v, w)), column-major, summed left to right (GLSL mat4*vec4).
@@ -245,6 +247,76 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
         out.rootChild = 0;
     }
     return "";
+}
+
+// The two-level nodes (WNode) of a compacted tree, numbered breadth-first like the binary ones.  Returns false — and
+// leaves out.wnodes empty — when the tree does not qualify: its root is a leaf, its boxes are not nested (an uploaded
+// tree that is not the reference builder's: skipping a level would then skip a test the reference makes), its boxes do not
+// contain their triangles, or it is so deep that three pending siblings per wide level could outgrow the 64-entry stack.
+static inline bool derive_wide(CompactScene& out) {
+    out.wnodes.clear(); out.wideDepth = 0;
+    if (out.rootChild < 0 || out.nodes.empty() || !out.boxesContainTris) return false;
+    const size_t nb = out.nodes.size();
+    std::vector<int32_t> wideOf(nb, -1);
+    std::vector<uint32_t> order, depthOf;                    // binary indices that head a wide node, breadth-first
+    order.push_back((uint32_t)out.rootChild); depthOf.push_back(1);
+    wideOf[(size_t)out.rootChild] = 0;
+    auto inside = [](const float* lo, const float* hi, const float* plo, const float* phi) {
+        for (int k = 0; k < 3; k++) if (!(plo[k] <= lo[k] && hi[k] <= phi[k])) return false;
+        return true;
+    };
+    for (size_t head = 0; head < order.size(); head++) {
+        const CNode& N = out.nodes[order[head]];
+        out.wideDepth = std::max(out.wideDepth, depthOf[head]);
+        const int32_t ch[2] = {N.child0, N.child1};
+        for (int i = 0; i < 2; i++) {
+            if (ch[i] < 0) continue;
+            const CNode& C = out.nodes[(size_t)ch[i]];
+            const float* plo = i ? N.lo1 : N.lo0; const float* phi = i ? N.hi1 : N.hi0;
+            const int32_t g[2] = {C.child0, C.child1};
+            for (int j = 0; j < 2; j++) {
+                if (g[j] < 0) continue;
+                const float* lo = j ? C.lo1 : C.lo0; const float* hi = j ? C.hi1 : C.hi0;
+                if (!inside(lo, hi, plo, phi)) { out.wideDepth = 0; return false; }      // not nested
+                wideOf[(size_t)g[j]] = (int32_t)order.size();
+                order.push_back((uint32_t)g[j]); depthOf.push_back(depthOf[head] + 1);
+            }
+        }
+    }
+    if (3u * out.wideDepth + 1u > 64u) { out.wideDepth = 0; return false; }       // too deep for the 64-entry stack
+    out.wnodes.resize(order.size());
+    for (size_t w = 0; w < order.size(); w++) {
+        WNode& W = out.wnodes[w];
+        std::memset(&W, 0, sizeof W);
+        int ns = 0;
+        auto put = [&](const float* lo, const float* hi, int32_t ref) {
+            for (int k = 0; k < 3; k++) { W.box[ns][k] = lo[k]; W.box[ns][3 + k] = hi[k]; }
+            W.ref[ns++] = ref;
+        };
+        const CNode& N = out.nodes[order[w]];
+        const int32_t ch[2] = {N.child0, N.child1};
+        for (int i = 0; i < 2; i++) {
+            const float* plo = i ? N.lo1 : N.lo0; const float* phi = i ? N.hi1 : N.hi0;
+            if (ch[i] == -1) continue;                                        // absent child
+            if (ch[i] < 0) { put(plo, phi, ch[i]); continue; }                // a child that is a leaf: its padded bounds, as in the binary node
+            const CNode& C = out.nodes[(size_t)ch[i]];
+            const int32_t g[2] = {C.child0, C.child1};
+            for (int j = 0; j < 2; j++) {
+                const float* lo = j ? C.lo1 : C.lo0; const float* hi = j ? C.hi1 : C.hi0;
+                if (g[j] == -1) continue;
+                if (g[j] >= 0) { put(lo, hi, wideOf[(size_t)g[j]]); continue; }
+                // a leaf two levels down: its padded bounds clipped to the box of the child above it, whose test this slot stands for
+                float clo[3], chi[3];
+                for (int k = 0; k < 3; k++) { clo[k] = std::max(lo[k], plo[k]); chi[k] = std::min(hi[k], phi[k]); }
+                put(clo, chi, g[j]);
+            }
+        }
+        for (; ns < 4; ns++) {
+            for (int k = 0; k < 3; k++) { W.box[ns][k] = FLT_MAX; W.box[ns][3 + k] = -FLT_MAX; }
+            W.ref[ns] = -1;
+        }
+    }
+    return true;
 }
 
 }  // namespace rt

@@ -61,7 +61,7 @@ struct rt_ctx {
     int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64;
 
     // device scene
-    DevBuf dNodes, dTris, dShade, dShadeUV, dMaterials, dCMat, dVertices, dLights, dTexDescs;
+    DevBuf dNodes, dWNodes, dTris, dShade, dShadeUV, dMaterials, dCMat, dVertices, dLights, dTexDescs;
     std::vector<Texture> textures;
     CompactScene cs;
     uint64_t nLights = 0, nMaterials = 0;
@@ -97,6 +97,9 @@ struct rt_ctx {
     int32_t kernelChoice = -1;  // >= 0: this combination (bit 0 / bit 1 as tuneChoice) whatever was measured: every rank of a
                                 // multi-GPU job is given rank 0's choice, so that shards cost the same everywhere
     int32_t sunKernel = 1;      // 0: the general k_shadow also for one-sun scenes (A/B knob)
+    // wideNodes != 0: the refill kernels walk two-level nodes (WNode) derived from the same tree, when it qualifies (derive_wide)
+    int32_t wideNodes = 0;
+    bool wideReady = false;     // derive_wide has run for the scene on the device (its result may be "does not qualify")
     bool anyTextured = true, anyTransmissive = true;   // which k_shade variant the scene needs (set with the materials)
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
 
@@ -158,6 +161,15 @@ rt_status sync_scene(rt_ctx* c) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->sceneDirty = false;
         c->tuneState = 0; c->tuneChoice = 0;
+        c->wideReady = false; c->cs.wnodes.clear(); c->cs.wideDepth = 0;
+    }
+    if (c->wideNodes != 0 && !c->wideReady) {
+        if (derive_wide(c->cs)) {
+            rt_status s = upload(c, c->dWNodes, c->cs.wnodes.data(), c->cs.wnodes.size() * sizeof(WNode));
+            if (s) return s;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        c->wideReady = true;
     }
     if (c->materialsDirty) {
         const auto& M = c->slotHost[RT_SLOT_MATERIALS];
@@ -218,6 +230,7 @@ SceneView make_view(rt_ctx* c, bool exact) {
     for (int k = 0; k < 3; k++) { S.rootLo[k] = c->cs.rootLo[k]; S.rootHi[k] = c->cs.rootHi[k]; }
     S.cullAbs = 1e-5f * c->cs.sceneScale;
     S.exactMode = exact ? 1 : 0;
+    S.wnodes = (!exact && c->wideNodes != 0 && c->wideReady && !c->cs.wnodes.empty()) ? (const WNode*)c->dWNodes.p : nullptr;
     return S;
 }
 
@@ -251,8 +264,9 @@ uint32_t stack_blocks(rt_ctx* c, uint32_t nslots) {
     return std::max(1u, slotBlocks < most ? slotBlocks : most);
 }
 uint32_t overflow_depth(rt_ctx* c) {
-    // ordered traversal keeps at most one pending sibling per level: depth <= tree depth
+    // ordered traversal keeps at most one pending sibling per level: depth <= tree depth (two-level nodes: three per level)
     int need = (int)c->cs.maxDepth + 1 - RT_LDS_STACK;
+    if (!c->cs.wnodes.empty()) need = std::max(need, 3 * (int)c->cs.wideDepth + 1 - RT_LDS_STACK);
     if (need < 0) need = 0;
     if (need > RT_SPILL_STACK) need = RT_SPILL_STACK;
     return (uint32_t)need;
@@ -416,6 +430,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const int combo = exact ? 0 : c->refill > 0 ? 3 : c->refill == 0 ? 0 : c->kernelChoice >= 0 ? (c->kernelChoice & 3) : c->tuneState >= 4 ? c->tuneChoice
                     : trial ? kTuneTrial[c->tuneState] : comboDefault;
     const bool refillExtend = (combo & 1) != 0, refillShadow = (combo & 2) != 0;
+    const bool wide = S.wnodes != nullptr;
     const int refillIdle = std::min(64, std::max(1, (int)c->refillIdle));
     const int refillNodeMin = std::min(64, std::max(1, (int)c->refillNodeMin)) | (std::min(64, std::max(0, (int)c->refillTriMin)) << 8) |
                               (std::min(64, std::max(0, (int)c->refillNodeLow)) << 16) | ((c->refillDefer != 0 ? 1 : 0) << 24);
@@ -481,7 +496,11 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                 e = evBegin(b == 0 ? 3 : 0);
                 if (refillExtend && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
                     const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
-                    if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
+                    if (wide) {
+                        if (count) k_extend_refill<true, false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
+                        else k_extend_refill<false, false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
+                    }
+                    else if (count) k_extend_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
                     else k_extend_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
                 }
                 else if (b == 0) launch_extend<true>(exact, count, dim3(tb), st, S, F, Pp, (const float4*)nullptr, (const uint32_t*)qcount, (int)rBase, inPass * w * h, dst);
@@ -510,9 +529,15 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                     const int shd = refillShadow ? (sun1 ? 3 : 2) : (sun1 ? 1 : 0);
                     e = evBegin(0);
 #define RT_PAIR(EXT, SHD) k_trace_pair<EXT, SHD><<<g, RT_BLOCK, 0, st>>>(S, F, Pp, qnext, cE, (int)rBase, cS, (int)b, gE, gS, refillIdle, refillNodeMin, dst)
-                    if (refillExtend) { if (shd == 0) RT_PAIR(1, 0); else if (shd == 1) RT_PAIR(1, 1); else if (shd == 2) RT_PAIR(1, 2); else RT_PAIR(1, 3); }
+#define RT_PAIRW(EXT, SHD) k_trace_pair<EXT, SHD, true><<<g, RT_BLOCK, 0, st>>>(S, F, Pp, qnext, cE, (int)rBase, cS, (int)b, gE, gS, refillIdle, refillNodeMin, dst)
+                    if (wide && (refillExtend || refillShadow)) {
+                        if (refillExtend) { if (shd == 0) RT_PAIRW(1, 0); else if (shd == 1) RT_PAIRW(1, 1); else if (shd == 2) RT_PAIRW(1, 2); else RT_PAIRW(1, 3); }
+                        else { if (shd == 2) RT_PAIRW(0, 2); else RT_PAIRW(0, 3); }
+                    }
+                    else if (refillExtend) { if (shd == 0) RT_PAIR(1, 0); else if (shd == 1) RT_PAIR(1, 1); else if (shd == 2) RT_PAIR(1, 2); else RT_PAIR(1, 3); }
                     else { if (shd == 0) RT_PAIR(0, 0); else if (shd == 1) RT_PAIR(0, 1); else if (shd == 2) RT_PAIR(0, 2); else RT_PAIR(0, 3); }
 #undef RT_PAIR
+#undef RT_PAIRW
                     evEnd(e);
                     nPairs++;
                     extendDone = true;
@@ -521,7 +546,12 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                 e = evBegin(2);
                 if (refillShadow) {
                     const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
-                    if (count) k_shadow_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
+                    if (wide) {
+                        if (count) k_shadow_refill<true, false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
+                        else if (sun1) k_shadow_refill<false, true, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
+                        else k_shadow_refill<false, false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
+                    }
+                    else if (count) k_shadow_refill<true, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
                     else if (sun1) k_shadow_refill<false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
                     else k_shadow_refill<false, false><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
                 }
@@ -697,7 +727,7 @@ void rt_destroy(rt_ctx* c) {
     for (hipEvent_t ev : c->evResolve) if (ev) (void)hipEventDestroy(ev);
     if (c->evInit) (void)hipEventDestroy(c->evInit);
     for (hipStream_t x : c->extra) if (x) (void)hipStreamDestroy(x);
-    DevBuf* bufs[] = {&c->dNodes, &c->dTris, &c->dShade, &c->dShadeUV, &c->dCMat, &c->dMaterials, &c->dVertices, &c->dLights, &c->dTexDescs,
+    DevBuf* bufs[] = {&c->dNodes, &c->dWNodes, &c->dTris, &c->dShade, &c->dShadeUV, &c->dCMat, &c->dMaterials, &c->dVertices, &c->dLights, &c->dTexDescs,
                       &c->img[0], &c->img[1], &c->img[2], &c->img[3], &c->primTri, &c->primHit, &c->accum, &c->dStats, &c->rgbStage};
     for (DevBuf* b : bufs) b->release();
     for (auto& t : c->textures) t.data.release();
@@ -738,6 +768,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "refillTriMin")) c->refillTriMin = v;
     else if (name_is(name, "refillNodeLow")) c->refillNodeLow = v;
     else if (name_is(name, "refillDefer")) c->refillDefer = v;
+    else if (name_is(name, "wideNodes")) c->wideNodes = v;
     else if (name_is(name, "sunKernel")) c->sunKernel = v;
     else if (name_is(name, "kernelChoice")) c->kernelChoice = v < 0 ? -1 : (v & 3);
     else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 0 ? 0 : v;

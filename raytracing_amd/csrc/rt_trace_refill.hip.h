@@ -83,6 +83,36 @@ __device__ __forceinline__ void slab_pair_s(v3 o, v3 inv, float4 n0, float4 n1, 
     tx1 = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fmaxf(cz, dz));
 }
 
+// One visit of a two-level node (WNode, rt_types.h): the slab test of slab_pair_s on each of its four slots, then the
+// slots the ray passes sorted by entry distance.  r[k] = the k-th nearest passing slot's reference (RT_DONE from the
+// first slot on that did not pass), t[k] its entry distance.  LIM: cull slots that start beyond `lim`.
+template <bool LIM>
+__device__ __forceinline__ void wide_visit(const WNode* __restrict__ wn, v3 o, v3 inv, float lim, int (&r)[4], float (&t)[4]) {
+    const float4* np = reinterpret_cast<const float4*>(wn);
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4], n5 = np[5], n6 = np[6];
+    const float INF = __int_as_float(0x7f800000);
+#define RT_WSLOT(k, lx, ly, lz, hx, hy, hz, rf)                                                                  \
+    {                                                                                                           \
+        const float ax = ((lx) - o.x) * inv.x, ay = ((ly) - o.y) * inv.y, az = ((lz) - o.z) * inv.z;            \
+        const float bx = ((hx) - o.x) * inv.x, by = ((hy) - o.y) * inv.y, bz = ((hz) - o.z) * inv.z;            \
+        const float te = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));                             \
+        const float tx = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));                             \
+        const int ref = __float_as_int(rf);                                                                     \
+        const bool p = tx >= te && tx >= 0.0f && (!LIM || !(te > lim)) && ref != -1;                            \
+        r[k] = p ? ref : RT_DONE;                                                                               \
+        t[k] = p ? fminf(te, 3.40282347e+38f) : INF;     /* a passing slot always sorts in front of the others */ \
+    }
+    RT_WSLOT(0, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n6.x)
+    RT_WSLOT(1, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n6.y)
+    RT_WSLOT(2, n3.x, n3.y, n3.z, n3.w, n4.x, n4.y, n6.z)
+    RT_WSLOT(3, n4.z, n4.w, n5.x, n5.y, n5.z, n5.w, n6.w)
+#undef RT_WSLOT
+#define RT_WCE(a, b) { const bool sw = t[b] < t[a]; const float ta = t[a]; const int ra = r[a];                  \
+                       t[a] = sw ? t[b] : ta; r[a] = sw ? r[b] : ra; t[b] = sw ? ta : t[b]; r[b] = sw ? ra : r[b]; }
+    RT_WCE(0, 1) RT_WCE(2, 3) RT_WCE(0, 2) RT_WCE(1, 3) RT_WCE(1, 2)
+#undef RT_WCE
+}
+
 // Closest hit == lineCast (shader.comp:243-290) for the rays of `queue` (PRIMARY: the camera rays of all slots).
 //
 // Ray set-up (fetch, 1/d, root box) is done for a whole 64-ray group at a time with every lane of the wave working,
@@ -108,7 +138,8 @@ __device__ __forceinline__ RefillSched unpack_sched(int v) {
     return r;
 }
 typedef float RayPool[RT_POOL_WORDS][64];      // one wave's pool of prepared rays
-template <bool COUNT, bool PRIMARY>
+// WIDE: walk the two-level nodes (S.wnodes) instead of the binary ones — half the dependent fetches per ray.
+template <bool COUNT, bool PRIMARY, bool WIDE = false>
 __device__ __forceinline__ void extend_refill(const SceneView& S, const FrameParams& F, const PathBuffers& P,
                                               const float4* __restrict__ rays, const uint32_t* __restrict__ count,
                                               int rBase, uint32_t rayCount, int refillIdle, int schedBits,
@@ -249,7 +280,16 @@ __device__ __forceinline__ void extend_refill(const SceneView& S, const FramePar
                         break;
                     }
                 }
-                if (hasNode) {
+                if (hasNode && WIDE) {
+                    // (a wide visit counts as two node visits: it fetches two node records' worth, 128 bytes)
+                    if (COUNT) { nNodes += 2; bNodes += 2; if (first_active_lane()) { wNode += 2; if (!canRefill) { dbg2[0]++; dbg2[1] += (uint32_t)nNode; } } }
+                    int r[4]; float t[4];
+                    wide_visit<true>(S.wnodes + cur, o, rinv, lim, r, t);
+                    for (int k = 3; k >= 1; k--)      // the farther slots wait on the stack, nearest on top
+                        if (r[k] != RT_DONE) { uint2 e; e.x = (uint32_t)r[k]; e.y = __float_as_uint(t[k]); stk.push(sp, e); }
+                    if (r[0] != RT_DONE) cur = r[0]; else popNext();
+                    if (cur < 0 && cur != RT_DONE && pend == RT_DONE) { pend = cur; popNext(); }
+                } else if (hasNode) {
                     const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
                     float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                     if (COUNT) { nNodes++; bNodes++; if (first_active_lane()) { wNode++; if (!canRefill) { dbg2[0]++; dbg2[1] += (uint32_t)nNode; } } }
@@ -339,21 +379,21 @@ __device__ __forceinline__ void extend_refill(const SceneView& S, const FramePar
     }
 }
 
-template <bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(RT_BLOCK, 6) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
+template <bool COUNT, bool PRIMARY, bool WIDE = false>
+__global__ __launch_bounds__(RT_BLOCK, (WIDE ? 5 : 6)) void k_extend_refill(SceneView S, FrameParams F, PathBuffers P,
                                                          const float4* __restrict__ rays, const uint32_t* __restrict__ count,
                                                          int rBase, uint32_t rayCount, int refillIdle, int schedBits,
                                                          DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
     __shared__ RayPool poolMem[RT_BLOCK / 64];
-    extend_refill<COUNT, PRIMARY>(S, F, P, rays, count, rBase, rayCount, refillIdle, schedBits, stats, lds, poolMem, blockIdx.x, gridDim.x);
+    extend_refill<COUNT, PRIMARY, WIDE>(S, F, P, rays, count, rBase, rayCount, refillIdle, schedBits, stats, lds, poolMem, blockIdx.x, gridDim.x);
 }
 
 // shader.comp:453-484: the shadow lineCast of every log entry awaiting one; the entry becomes "add" (2) or "none" (0).
 // Work item i = (shadow-queue entry i / numLights, light i % numLights).
 // SUN1: exactly one light and it is a sun — no point-light state is carried (fewer registers, more resident waves, which is
 // what a miss-latency-bound kernel wants) and the direction's reciprocal is computed once per thread.
-template <bool COUNT, bool SUN1>
+template <bool COUNT, bool SUN1, bool WIDE = false>
 __device__ __forceinline__ void shadow_refill(const SceneView& S, const FrameParams& F, const PathBuffers& P, const uint32_t* __restrict__ count,
                                               int bounce, int refillIdle, int schedBits, DeviceStats* stats, uint2* lds, uint32_t bid, uint32_t nblk) {
     const Stack stk = make_stack(lds, P);
@@ -475,7 +515,15 @@ __device__ __forceinline__ void shadow_refill(const SceneView& S, const FramePar
                     if (wantRefill && sched.defer && nParked < sched.triMin) { skipTris = true; break; }
                     if (nNode == 0 || wantTris || wantRefill) break;
                 }
-                if (hasNode) {
+                if (hasNode && WIDE) {
+                    if (COUNT) nNodes += 2;
+                    int r[4]; float t[4];
+                    if (SUN1) wide_visit<false>(S.wnodes + cur, o, rinv, 0.f, r, t); else wide_visit<true>(S.wnodes + cur, o, rinv, lim, r, t);
+                    for (int k = 3; k >= 1; k--)      // nearer slots first: an occluder, if any, tends to be found sooner
+                        if (r[k] != RT_DONE) { uint2 e; e.x = (uint32_t)r[k]; e.y = 0u; stk.push(sp, e); }
+                    if (r[0] != RT_DONE) cur = r[0]; else popS();
+                    if (cur < 0 && cur != RT_DONE && pend == RT_DONE) { pend = cur; popS(); }
+                } else if (hasNode) {
                     const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
                     float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                     if (COUNT) nNodes++;
@@ -534,11 +582,11 @@ __device__ __forceinline__ void shadow_refill(const SceneView& S, const FramePar
     }
 }
 
-template <bool COUNT, bool SUN1>
+template <bool COUNT, bool SUN1, bool WIDE = false>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FrameParams F, PathBuffers P, const uint32_t* __restrict__ count,
                                                          int bounce, int refillIdle, int schedBits, DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
-    shadow_refill<COUNT, SUN1>(S, F, P, count, bounce, refillIdle, schedBits, stats, lds, blockIdx.x, gridDim.x);
+    shadow_refill<COUNT, SUN1, WIDE>(S, F, P, count, bounce, refillIdle, schedBits, stats, lds, blockIdx.x, gridDim.x);
 }
 
 // The shadow rays of bounce b and the closest-hit rays of bounce b + 1 in ONE launch.  Both queues are written by
@@ -550,23 +598,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
 // Workgroup b of the launch runs the closest-hit body as workgroup b of a grid of gE, then the shadow body as workgroup
 // (gridDim - 1 - b) of a grid of gS: short queues therefore land on opposite ends of the launch and run side by side.
 // EXT: 0 extend_batch, 1 extend_refill.  SHD: 0 shadow_batch, 1 shadow_sun_batch, 2 shadow_refill<., false>, 3 shadow_refill<., true>.
-template <int EXT, int SHD>
-__global__ __launch_bounds__(RT_BLOCK, ((EXT == 1 && SHD != 2) ? 6 : 1)) void k_trace_pair(SceneView S, FrameParams F, PathBuffers P,
+// WIDE: the refill bodies walk the two-level nodes.
+template <int EXT, int SHD, bool WIDE = false>
+__global__ __launch_bounds__(RT_BLOCK, ((EXT == 1 && SHD != 2) ? (WIDE ? 5 : 6) : 1)) void k_trace_pair(SceneView S, FrameParams F, PathBuffers P,
                                                                           const float4* __restrict__ rays, const uint32_t* __restrict__ countExt,
                                                                           int rBase, const uint32_t* __restrict__ countShd, int bounceShd,
                                                                           uint32_t gE, uint32_t gS, int refillIdle, int schedBits, DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
     __shared__ RayPool poolMem[EXT == 1 ? RT_BLOCK / 64 : 1];
     if (blockIdx.x < gE) {
-        if (EXT == 1) extend_refill<false, false>(S, F, P, rays, countExt, rBase, 0u, refillIdle, schedBits, stats, lds, poolMem, blockIdx.x, gE);
+        if (EXT == 1) extend_refill<false, false, WIDE>(S, F, P, rays, countExt, rBase, 0u, refillIdle, schedBits, stats, lds, poolMem, blockIdx.x, gE);
         else extend_batch<false, false, false>(S, F, P, rays, countExt, rBase, 0u, stats, lds, blockIdx.x, gE);
     }
     const uint32_t bs = gridDim.x - 1u - blockIdx.x;
     if (bs < gS) {
         if (SHD == 0) shadow_batch<false, false>(S, F, P, countShd, bounceShd, stats, lds, bs, gS);
         else if (SHD == 1) shadow_sun_batch(S, F, P, countShd, bounceShd, lds, bs, gS);
-        else if (SHD == 2) shadow_refill<false, false>(S, F, P, countShd, bounceShd, refillIdle, schedBits, stats, lds, bs, gS);
-        else shadow_refill<false, true>(S, F, P, countShd, bounceShd, refillIdle, schedBits, stats, lds, bs, gS);
+        else if (SHD == 2) shadow_refill<false, false, WIDE>(S, F, P, countShd, bounceShd, refillIdle, schedBits, stats, lds, bs, gS);
+        else shadow_refill<false, true, WIDE>(S, F, P, countShd, bounceShd, refillIdle, schedBits, stats, lds, bs, gS);
     }
 }
 

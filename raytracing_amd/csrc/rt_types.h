@@ -72,6 +72,19 @@ struct CNode {
 };
 static_assert(sizeof(CNode) == 64, "CNode");
 
+// Wide node: TWO levels of the reference tree per fetch.  A slot is a grandchild of the binary node the record stands for
+// (or a child that is a leaf), with the box that gates it: the reference's own box of that grandchild if it is an internal
+// node, the padded world bounds of a leaf clipped to the box of the child above it.  The child's own box needs no test:
+// the reference's boxes are nested (a parent's box is the exact union of its children's) and the slab test is monotone
+// in the box bounds under IEEE rounding, so a ray that passes a grandchild's box passes the child's.
+//   ref >= 0 : index of the slot's WNode;  ref < -1 : leaf code as in CNode;  ref == -1 : empty slot (inverted box)
+struct WNode {
+    float box[4][6];               // slot k: lo.xyz, hi.xyz
+    int32_t ref[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(WNode) == 128, "WNode");
+
 // Pre-transformed triangle in reference visit order (right-child-first DFS, leaf slots in order), so
 // the array index is the reference's visit rank and a leaf is a contiguous run.
 struct CTri {
@@ -130,6 +143,7 @@ struct SceneView {
     float rootLo[3], rootHi[3];    // reference box of node 0 (tested first, shader.comp:249-256)
     float cullAbs;                 // absolute slack of the distance cull (traversalMode 0)
     int32_t exactMode;             // 1 = reference-order exhaustive traversal
+    const WNode* wnodes;           // two-level nodes of the same tree (null: not derived for this scene); root = wnodes[0]
 };
 
 struct FrameParams {

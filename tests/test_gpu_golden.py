@@ -20,7 +20,11 @@ VARIANTS = {"culled": {"traversalMode": 0}, "reference_order": {"traversalMode":
             # shadow rays of a bounce and closest-hit rays of the next in separate launches (the default traces them together),
             # and every pairing of batch / refill kernels in the joint launch
             "separate_launches": {"fusePairs": 0}, "pair_refill_batch": {"kernelChoice": 1}, "pair_batch_refill": {"kernelChoice": 2},
-            "pair_refill_refill": {"kernelChoice": 3, "refillBlocksPerCU": 2, "blocksPerCU": 3}}
+            "pair_refill_refill": {"kernelChoice": 3, "refillBlocksPerCU": 2, "blocksPerCU": 3},
+            # two-level nodes in the refill kernels: joint launches with either or both kinds, separate launches, eager refills
+            "wide_refill_refill": {"kernelChoice": 3, "wideNodes": 1}, "wide_refill_batch": {"kernelChoice": 1, "wideNodes": 1},
+            "wide_batch_refill": {"kernelChoice": 2, "wideNodes": 1},
+            "wide_separate": {"refill": 1, "refillIdle": 1, "fusePairs": 0, "wideNodes": 1}}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
