@@ -119,10 +119,7 @@ __device__ __forceinline__ void wide_visit(const WNode* __restrict__ wn, v3 o, v
 // whatever the lanes' own rays are doing, and the prepared rays wait in a per-wave LDS pool; a refill then costs an
 // idle lane a few LDS reads.  (Setting rays up inside the refill, with only the idle lanes active, made every refill
 // as expensive as a full wave's set-up.)
-#define RT_POOL_WORDS 7      // o.xyz, d.xyz, queue entry (1/d is formed again at hand-out: LDS is what limits resident workgroups)
-#ifndef RT_PACK_TRIS
-#define RT_PACK_TRIS 1       // 1: the triangle phase tests (ray, triangle) pairs spread over the whole wave
-#endif
+#define RT_POOL_WORDS 10     // o.xyz, d.xyz, 1/d.xyz, queue entry
 // Below `nodeMin` lanes with a node to visit, the node phase of the refill kernels goes on until RT_TRI_MIN lanes have a
 // leaf parked (so that the triangle phase runs with a fuller wave too) or fewer than RT_NODE_LOW lanes have a node
 // (measured 16/12, 32/8, 48/4: 32/8 best on C2..C5).
@@ -141,19 +138,13 @@ __device__ __forceinline__ RefillSched unpack_sched(int v) {
     return r;
 }
 typedef float RayPool[RT_POOL_WORDS][64];      // one wave's pool of prepared rays
-// Exchange area of the packed triangle phase, per wave: which (owner lane, triangle of its leaf) each lane tests, and per
-// owner lane the best hit so far as a 64-bit key — squared distance (a non-negative float: its bits order like the value)
-// above the triangle's visit rank — so that "nearer, or as near and earlier in visit order" is one unsigned minimum.
-struct PairMem { unsigned long long best[64]; uint8_t tab[64]; };
 // WIDE: walk the two-level nodes (S.wnodes) instead of the binary ones — half the dependent fetches per ray.
 template <bool COUNT, bool PRIMARY, bool WIDE = false>
 __device__ __forceinline__ void extend_refill(const SceneView& S, const FrameParams& F, const PathBuffers& P,
                                               const float4* __restrict__ rays, const uint32_t* __restrict__ count,
                                               int rBase, uint32_t rayCount, int refillIdle, int schedBits,
-                                              DeviceStats* stats, uint2* lds, RayPool* poolMem, PairMem* pairMem, uint32_t bid, uint32_t nblk) {
+                                              DeviceStats* stats, uint2* lds, RayPool* poolMem, uint32_t bid, uint32_t nblk) {
     const RefillSched sched = unpack_sched(schedBits);
-    uint8_t* tab = pairMem[threadIdx.x >> 6].tab;                  // this wave's (ray, triangle) pair table
-    unsigned long long* best64 = pairMem[threadIdx.x >> 6].best;   // and its rays' best hits so far, as (distance, triangle) keys
     const int nodeMin = sched.nodeMin;
     const Stack stk = make_stack(lds, P);
     float (*pool)[64] = poolMem[threadIdx.x >> 6];
@@ -226,7 +217,8 @@ __device__ __forceinline__ void extend_refill(const SceneView& S, const FramePar
                     const uint32_t e = lane_prefix(rm);
                     pool[0][e] = ro.x; pool[1][e] = ro.y; pool[2][e] = ro.z;
                     pool[3][e] = rd.x; pool[4][e] = rd.y; pool[5][e] = rd.z;
-                    pool[6][e] = __uint_as_float(plain ? i : (i | 0x80000000u));
+                    pool[6][e] = inv.x; pool[7][e] = inv.y; pool[8][e] = inv.z;
+                    pool[9][e] = __uint_as_float(plain ? i : (i | 0x80000000u));
                 }
                 poolN = (uint32_t)__popcll(rm);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -241,18 +233,16 @@ __device__ __forceinline__ void extend_refill(const SceneView& S, const FramePar
                 const uint32_t e = poolN - 1u - pre;
                 o = mk(pool[0][e], pool[1][e], pool[2][e]);
                 d = mk(pool[3][e], pool[4][e], pool[5][e]);
-                slot = __float_as_uint(pool[6][e]);
+                const v3 inv = mk(pool[6][e], pool[7][e], pool[8][e]);
+                slot = __float_as_uint(pool[9][e]);
                 if (slot & 0x80000000u) {
                     slot &= 0x7fffffffu;
                     HitRec best;
                     closest_hit<false, COUNT, false>(S, o, d, stk, best, nNodes, nTris);
                     P.hit[slot] = make_float2(best.t, __int_as_float(best.ref));
                 } else {
-                    rinv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    rinv = inv;
                     bestT = INF; bestDist = 3.40282347e+38f; lim = INF; bestIdx = -1; bestRef = -1;
-#if RT_PACK_TRIS
-                    best64[lane] = 0x7f7fffffffffffffull;      // (bestDist, bestIdx) as one key: FLT_MAX, no triangle
-#endif
                     sp = 0; cur = S.rootChild; pend = RT_DONE;
                     if (cur < 0) { pend = cur; cur = RT_DONE; }      // the root's only child is a leaf
                     if (COUNT) steps0 = nNodes + nTris;
@@ -322,70 +312,6 @@ __device__ __forceinline__ void extend_refill(const SceneView& S, const FramePar
             // Triangle phase: every lane with a parked leaf tests it; a second leaf waiting in `cur` is parked next.
             // (One triangle per phase instead of the whole leaf, so that a phase is as short as its shortest leaf, was
             // measured: 4 % slower.)
-#if RT_PACK_TRIS
-            // The parked leaves' triangles become (ray, triangle) pairs spread over all 64 lanes: a lane tests a pair for the
-            // ray's owner (ray fetched from the owner's registers with ds_bpermute) and, on a hit, lowers the owner's key in
-            // LDS; the owner then reads its key back.  The key's order is the update rule of the loop form below (nearer, or as
-            // near and earlier in visit order), which does not depend on the order of the tests.  One wave-level load triple
-            // so serves up to 64 pairs instead of one triangle of each parked lane.
-            {
-                const bool parked = !skipTris && pend != RT_DONE;
-                const int code = parked ? -pend - 1 : 0;
-                const int first = code >> 3;
-                const uint32_t cnt = (uint32_t)(code & 7);
-                const unsigned long long m0 = __ballot((cnt & 1u) != 0u), m1 = __ballot((cnt & 2u) != 0u), m2 = __ballot((cnt & 4u) != 0u);
-                const uint32_t pre = lane_prefix(m0) + 2u * lane_prefix(m1) + 4u * lane_prefix(m2);      // pairs of the lanes below
-                const uint32_t T = (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1) + 4u * (uint32_t)__popcll(m2);
-                if (COUNT) { nTris += cnt; bTris += cnt; }
-                for (uint32_t base = 0; base < T; base += 64u) {
-                    for (uint32_t k = 0; k < cnt; k++) { const uint32_t p = pre + k - base; if (p < 64u) tab[p] = (uint8_t)(lane | (k << 6)); }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const bool work = base + lane < T;
-                    const uint32_t e = work ? (uint32_t)tab[lane] : lane;
-                    const int owner = (int)(e & 63u);
-                    const v3 ro = mk(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
-                    const v3 rd = mk(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
-                    const int tri = __shfl(first, owner, 64) + (int)(e >> 6);
-                    float tHit = INF;
-                    if (work) {
-                        if (COUNT && first_active_lane()) { wTri++; if (!canRefill) { dbg2[2]++; dbg2[3] += (uint32_t)__popcll(__ballot(true)); } }
-                        const float4* tp = reinterpret_cast<const float4*>(S.tris + tri);
-                        float t;
-                        if (tri_t(tp[0], tp[1], tp[2], ro, rd, &t)) {
-                            v3 h = ro + rd * t;
-                            v3 oh = ro - h;
-                            float newDist = dot3(oh, oh);
-                            // (a distance of FLT_MAX or more, or NaN, never replaces the best hit in the loop form either)
-                            if (newDist < 3.40282347e+38f) {
-                                tHit = t;
-                                atomicMin(&best64[owner], ((unsigned long long)__float_as_uint(newDist) << 32) | (unsigned long long)(uint32_t)tri);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // the owner: did one of this round's pairs win?  Then its t comes from the lane that tested it.
-                    const unsigned long long key = parked ? best64[lane] : 0ull;
-                    const int wIdx = (int)(uint32_t)key;
-                    const uint32_t src = pre + (uint32_t)(wIdx - first) - base;
-                    const bool won = parked && wIdx != bestIdx && src < 64u;      // (the winner is one of this round's pairs: idx changed)
-                    const float t = __shfl(tHit, won ? (int)src : (int)lane, 64);
-                    if (won) {
-                        bestDist = __uint_as_float((uint32_t)(key >> 32)); bestIdx = wIdx; bestT = t;
-                        lim = bestT + bestT * 1e-4f + S.cullAbs;
-                    }
-                }
-                if (parked) {
-                    pend = RT_DONE;
-                    if (cur < 0 && cur != RT_DONE) { pend = cur; popNext(); }
-                }
-            }
-            if (active && cur == RT_DONE && pend == RT_DONE) {
-                if (bestIdx >= 0) bestRef = S.tris[bestIdx].refIndex;
-#else
             if (!skipTris && pend != RT_DONE) {
                 int code = -pend - 1;
                 int first = code >> 3, cnt = code & 7;
@@ -409,7 +335,6 @@ __device__ __forceinline__ void extend_refill(const SceneView& S, const FramePar
                 if (cur < 0 && cur != RT_DONE) { pend = cur; popNext(); }
             }
             if (active && cur == RT_DONE && pend == RT_DONE) {
-#endif
                 P.hit[slot] = make_float2(bestT, __int_as_float(bestRef));
                 if (COUNT) { uint32_t st = nNodes + nTris - steps0 + 1; if (st > maxSteps) maxSteps = st; }
                 active = false;
@@ -461,8 +386,7 @@ __global__ __launch_bounds__(RT_BLOCK, (WIDE ? 5 : 6)) void k_extend_refill(Scen
                                                          DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
     __shared__ RayPool poolMem[RT_BLOCK / 64];
-    __shared__ PairMem pairMem[RT_BLOCK / 64];
-    extend_refill<COUNT, PRIMARY, WIDE>(S, F, P, rays, count, rBase, rayCount, refillIdle, schedBits, stats, lds, poolMem, pairMem, blockIdx.x, gridDim.x);
+    extend_refill<COUNT, PRIMARY, WIDE>(S, F, P, rays, count, rBase, rayCount, refillIdle, schedBits, stats, lds, poolMem, blockIdx.x, gridDim.x);
 }
 
 // shader.comp:453-484: the shadow lineCast of every log entry awaiting one; the entry becomes "add" (2) or "none" (0).
@@ -682,9 +606,8 @@ __global__ __launch_bounds__(RT_BLOCK, ((EXT == 1 && SHD != 2) ? (WIDE ? 5 : 6) 
                                                                           uint32_t gE, uint32_t gS, int refillIdle, int schedBits, DeviceStats* stats) {
     __shared__ uint2 lds[RT_LDS_STACK * RT_BLOCK];
     __shared__ RayPool poolMem[EXT == 1 ? RT_BLOCK / 64 : 1];
-    __shared__ PairMem pairMem[EXT == 1 ? RT_BLOCK / 64 : 1];
     if (blockIdx.x < gE) {
-        if (EXT == 1) extend_refill<false, false, WIDE>(S, F, P, rays, countExt, rBase, 0u, refillIdle, schedBits, stats, lds, poolMem, pairMem, blockIdx.x, gE);
+        if (EXT == 1) extend_refill<false, false, WIDE>(S, F, P, rays, countExt, rBase, 0u, refillIdle, schedBits, stats, lds, poolMem, blockIdx.x, gE);
         else extend_batch<false, false, false>(S, F, P, rays, countExt, rBase, 0u, stats, lds, blockIdx.x, gE);
     }
     const uint32_t bs = gridDim.x - 1u - blockIdx.x;
