@@ -77,6 +77,15 @@ struct GpuSweep {
 };
 inline GpuSweep& gpu_sweep() { static GpuSweep g; return g; }
 
+// RT_BVH_TIMING=1: thread-time spent per phase (nanoseconds, summed over threads) and the wall time of the levels
+struct BuildTimes { std::atomic<long long> sortNs{0}, gatherNs{0}, sweepNs{0}, gpuNs{0}, splitNs{0}; bool on = false; };
+inline BuildTimes& build_times() { static BuildTimes t; return t; }
+struct PhaseTimer {
+    std::atomic<long long>* acc; std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(std::atomic<long long>& a) : acc(build_times().on ? &a : nullptr) { if (acc) t0 = std::chrono::steady_clock::now(); }
+    ~PhaseTimer() { if (acc) acc->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()); }
+};
+
 struct Builder {
     const Soa& S;
     std::atomic<int> freeWorkers;
@@ -148,9 +157,11 @@ struct Builder {
     // a NaN bound take the single-chunk path, see build_bvh.)
     AxisResult sweepSorted(const uint32_t* ids, size_t n) {
         if (useGpu && n >= gpu_sweep().minNode) {
+            PhaseTimer pt(build_times().gpuNs);
             AxisResult r;
             if (gpu_sweep().sweep(ids, n, &r.cost, &r.index)) return r;
         }
+        PhaseTimer pt(build_times().sweepNs);
         std::vector<B6> b(n), suf(n);
         const size_t chunks = (n >= ((size_t)1 << 17) && freeWorkers.load() >= 0 && !serialSweeps) ? std::min<size_t>(64, n >> 15) : 1;
         const size_t per = (n + chunks - 1) / chunks;
@@ -214,6 +225,7 @@ struct Builder {
         auto doAxis = [&](int a) {
             if (distinct[a]) order[a] = std::move(pre[a]);
             else {
+                PhaseTimer pt(build_times().sortNs);
                 std::vector<KeyId> sorted(n);
                 const float* cen = S.cen[a].data();
                 for (size_t i = 0; i < n; i++) { sorted[i].key = cen[ids[i]]; sorted[i].id = ids[i]; }
@@ -321,6 +333,12 @@ inline std::vector<RefNode> build_bvh(const RefTriangle* tris, size_t n, int wor
     for (int a = 0; a < 3; a++) S.cen[a].resize(n);
     S.box.resize(n);
     if (workers <= 0) workers = default_workers();
+    BuildTimes& BT = build_times();
+    BT.on = std::getenv("RT_BVH_TIMING") != nullptr;
+    BT.sortNs = 0; BT.gatherNs = 0; BT.sweepNs = 0; BT.gpuNs = 0; BT.splitNs = 0;
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto wall = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(); };
+    double tSetup = 0, tProbe = 0, tBuild = 0, tFlat = 0;
     Builder B(S, workers - 1);
     std::atomic<bool> nan{false};
     B.parallelChunks(n, n >= ((size_t)1 << 18) ? 32 : 1, [&](size_t, size_t b, size_t e) {
@@ -338,14 +356,25 @@ inline std::vector<RefNode> build_bvh(const RefTriangle* tris, size_t n, int wor
     std::vector<uint32_t> ids(n);
     for (size_t i = 0; i < n; i++) ids[i] = (uint32_t)i;
     std::vector<uint32_t> pre[3];
+    tSetup = wall();
     // With a NaN anywhere the `?:` min / max and the comparator stop being order-independent: such a scene is built
     // exactly as the reference writes it (sequential sweeps, a sort per node and axis, no device sweeps).
     if (nan) B.serialSweeps = true;
     else if (n > 4 && !std::getenv("RT_BVH_NO_PRESORT")) {
         // which axes have pairwise distinct keys: one sort of the whole scene per axis (any correct sort will do here)
         auto probe = [&](int a) {
-            std::vector<KeyId> k(n);
             const float* cen = S.cen[a].data();
+            // a strided sample first: a grid-aligned scene (config 4's field on x and z) shows its ties in a few thousand
+            // keys, and the scene-wide sort is then not worth making
+            if (n > ((size_t)1 << 20)) {
+                const size_t step = n >> 18;
+                std::vector<float> smp;
+                smp.reserve(n / step + 1);
+                for (size_t i = 0; i < n; i += step) smp.push_back(cen[i]);
+                std::sort(smp.begin(), smp.end());
+                for (size_t i = 1; i < smp.size(); i++) if (!(smp[i - 1] < smp[i])) { B.distinct[a] = false; return; }
+            }
+            std::vector<KeyId> k(n);
             for (size_t i = 0; i < n; i++) { k[i].key = cen[i]; k[i].id = (uint32_t)i; }
             B.stdSortPar(k.begin(), k.end(), [](const KeyId& x, const KeyId& y) { return x.key < y.key; });
             bool dist = true;
@@ -362,15 +391,21 @@ inline std::vector<RefNode> build_bvh(const RefTriangle* tris, size_t n, int wor
         } else for (int a = 0; a < 3; a++) probe(a);
         if (B.distinct[0] || B.distinct[1] || B.distinct[2]) B.side.assign(n, 0);
     }
+    tProbe = wall();
     GpuSweep& G = gpu_sweep();
     B.useGpu = allowGpu && !nan && G.begin && G.sweep && n >= G.minNode && !std::getenv("RT_BVH_NO_GPU") && G.begin(S.box.data(), n);
     std::unique_ptr<Node> root;
     try { root = B.build(std::move(ids), pre, 0); }
     catch (...) { if (B.useGpu && G.end) G.end(); throw; }
     if (B.useGpu && G.end) G.end();
+    tBuild = wall();
     std::vector<RefNode> out;
     out.reserve(n);
     flatten(root.get(), out);
+    tFlat = wall();
+    if (BT.on)
+        std::fprintf(stderr, "[bvh] %zu triangles, %d workers, gpu sweeps %d: wall setup %.3f probe %.3f build %.3f flatten %.3f s; thread time sort %.3f host sweep %.3f gpu sweep %.3f s\n",
+                     n, workers, (int)B.useGpu, tSetup, tProbe - tSetup, tBuild - tProbe, tFlat - tBuild, BT.sortNs.load() * 1e-9, BT.sweepNs.load() * 1e-9, BT.gpuNs.load() * 1e-9);
     // deep trees: release iteratively to keep the destructor recursion shallow
     std::vector<std::unique_ptr<Node>> pend;
     pend.push_back(std::move(root));
