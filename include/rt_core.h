@@ -159,6 +159,8 @@ typedef struct rt_stats {
     int32_t  kernel_choice_settled;  /* 1: fixed by a knob or by the finished per-scene trial; 0: a trial frame or the default */
     uint64_t launches_pair;    /* launches that traced the shadow rays of a bounce and the closest-hit rays of the next together
                                   (k_trace_pair, knob fusePairs); they are counted and timed under launches_extend / ms_extend */
+    int32_t  wide_nodes;       /* 1: the refill kernels of this call walked two-level nodes (knob wideNodes and a tree that qualifies) */
+    int32_t  wide_depth;       /* two-level steps on the longest root-to-leaf path (0: not derived) */
 } rt_stats;
 rt_status rt_get_stats(rt_ctx* ctx, rt_stats* out);
 

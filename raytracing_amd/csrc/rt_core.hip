@@ -630,6 +630,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.launches_extend = nLaunch[0] + nLaunch[3]; c->stats.launches_shade = nLaunch[1]; c->stats.launches_shadow = nLaunch[2];
     c->stats.ms_extend_primary = msAcc[3]; c->stats.launches_extend_primary = nLaunch[3];
     c->stats.launches_pair = nPairs;
+    c->stats.wide_nodes = (wide && (refillExtend || refillShadow)) ? 1 : 0;
+    c->stats.wide_depth = (int32_t)c->cs.wideDepth;
     c->stats.kernel_choice = exact ? -2 : combo;
     c->stats.kernel_choice_settled = (exact || c->refill >= 0 || c->kernelChoice >= 0 || c->tuneState >= 4) ? 1 : 0;
     c->primValid = aov;

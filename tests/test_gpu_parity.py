@@ -149,6 +149,7 @@ def test_million_random_rays_both_modes(scenes):
 
 
 @pytest.mark.parametrize("knobs", [{}, {"refill": 1}, {"refill": 1, "refillIdle": 1, "refillBlocksPerCU": 1}, {"traversalMode": 1},
+                                   {"refill": 1, "wideNodes": 1}, {"kernelChoice": 3, "wideNodes": 1, "refillIdle": 1, "refillNodeMin": 1},
                                    {"refill": 1, "refillNodeMin": 1}, {"refill": 1, "refillNodeMin": 64, "refillIdle": 64},
                                    {"refill": 1, "refillNodeMin": 64, "refillIdle": 1, "passStreams": 1},
                                    {"refill": 1, "refillDefer": 1, "refillTriMin": 8, "refillNodeLow": 2}])
@@ -337,7 +338,7 @@ def test_non_identity_mesh_matrices_bit_exact(oracle_lib, scenes, kind):
     cs.Delete()
 
 
-def _chain_scene(oracle_lib, n_tris):
+def _chain_scene(oracle_lib, n_tris, tweak=None):
     """n_tris small camera-facing triangles on a 10-wide grid under a degenerate BVH: internal node k = (leaf k, internal
     k + 1), the chain hanging off children.y — the child the shader pops first, so one pending sibling per level piles up
     on its 64-entry stack (shader.comp:246,281-284)."""
@@ -367,6 +368,8 @@ def _chain_scene(oracle_lib, n_tris):
         nodes[2 * k]["children"] = (2 * k + 1, 2 * k + 2, -1, -1)
         leaf(2 * k + 1, k)
     leaf(2 * n_tris - 2, n_tris - 1)
+    if tweak:
+        tweak(nodes)
     mats = np.zeros(1, G.MATERIAL_DT)
     mats["baseColorFactor"], mats["metallicFactor"], mats["roughnessFactor"], mats["ior"] = (0.8, 0.6, 0.4, 1.0), 0.0, 0.5, -1.0
     lights, has_sun = G.lights_to_gpu([((0, 0, 0), (0.2, -0.3, -1.0), 1, 1.0)])
@@ -403,6 +406,34 @@ def test_tree_deeper_than_the_reference_stack(oracle_lib, mode):
     setup_core(cs, sc2, W, H, spp, b)
     cs.dispatch()
     assert same_floats(cs.get_image(0), want2["color"]).all()
+    cs.Delete()
+
+
+def test_two_level_nodes_only_for_trees_that_qualify(oracle_lib):
+    """wideNodes: a 40-level chain is walked as 20 two-level steps with three pending siblings per step on the stack (61
+    entries: the LDS part and most of the overflow area); a 50-level chain would need 76 and a tree whose boxes are not
+    nested would skip a test the reference makes: both keep the binary nodes.  Same images as the oracle's every time."""
+    from raytracing_amd import ComputeShader
+    W, H, spp, b = 160, 96, 2, 3
+
+    def not_nested(nodes):
+        # internal node 6, wider than the node above it — whose own test a two-level step starting at node 4 would skip
+        nodes[2 * 6]["minLoc"], nodes[2 * 6]["maxLoc"] = (-7, -1, -1), (7, 9, 1)
+
+    cs = ComputeShader()
+    for n, tweak, wide, depth in ((40, None, 1, 20), (50, None, 0, 0), (40, not_nested, 0, 0)):
+        sc = _chain_scene(oracle_lib, n, tweak)
+        want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
+        setup_core(cs, sc, W, H, spp, b)
+        cs.setInt("refill", 1)
+        cs.setInt("wideNodes", 1)
+        cs.dispatch()
+        st = cs.stats()
+        assert (st["wide_nodes"], st["wide_depth"]) == (wide, depth), (n, st["wide_nodes"], st["wide_depth"])
+        assert st["kernel_choice"] == 3
+        for k, name in enumerate(("color", "albedo", "normal", "depth")):
+            assert same_floats(cs.get_image(k), want[name]).all(), (n, name)
+        assert np.array_equal(cs.primary_hits()[0], want["prim_tri"])
     cs.Delete()
 
 
