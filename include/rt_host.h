@@ -55,7 +55,10 @@ void rth_orbit_camera(int32_t frame, float position_out[3], float orientation_ou
  * truncates to 8 bits, flips vertically; rgba8_out = W*H*4 bytes, top row first. */
 rt_status rth_frame_rgba8(rt_ctx* ctx, uint32_t width, uint32_t height, uint8_t* rgba8_out);
 
-/* PNG -> RGBA8 as Texture.cpp:5-34 uploads it (row 0 = first row of the file).  malloc'ed; rth_free. */
+/* Texture file (PNG or JPEG, told apart by content as stbi_load does) -> RGBA8 as Texture.cpp:5-34 uploads it (row 0 =
+ * first row of the file; 3 channels get A = 255, 1 channel lands in R alone).  malloc'ed; rth_free.
+ * rth_decode_png is the older name of the same call. */
+rt_status rth_decode_image(const char* path, uint8_t** rgba8_out, uint32_t* w, uint32_t* h);
 rt_status rth_decode_png(const char* path, uint8_t** rgba8_out, uint32_t* w, uint32_t* h);
 
 #ifdef __cplusplus

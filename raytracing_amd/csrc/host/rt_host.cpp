@@ -197,7 +197,7 @@ void Model::getTextures() {
         for (int i = 0; i < 3; i++) {
             if (indexList[i] == -1) continue;
             std::string texPath = JSON["images"][(size_t)indexList[i]]["uri"].string();   // texture index used as image index (Q15)
-            ImageRGBA8 im = decode_png(read_file_bytes(dir + texPath));
+            ImageRGBA8 im = decode_image(read_file_bytes(dir + texPath));      // stbi_load: PNG or JPEG by content
             uint64_t handle = 0;
             if (g_dry) handle = ++g_dryHandles;
             else {
@@ -565,10 +565,12 @@ rt_status rth_frame_rgba8(rt_ctx* ctx, uint32_t width, uint32_t height, uint8_t*
     });
 }
 
-rt_status rth_decode_png(const char* path, uint8_t** rgba8_out, uint32_t* w, uint32_t* h) {
+rt_status rth_decode_png(const char* path, uint8_t** rgba8_out, uint32_t* w, uint32_t* h) { return rth_decode_image(path, rgba8_out, w, h); }
+
+rt_status rth_decode_image(const char* path, uint8_t** rgba8_out, uint32_t* w, uint32_t* h) {
     if (!path || !rgba8_out || !w || !h) { g_err = "NULL argument"; return RT_ERR_INVALID; }
     return guarded([&] {
-        ImageRGBA8 im = decode_png(read_file_bytes(path));
+        ImageRGBA8 im = decode_image(read_file_bytes(path));
         uint8_t* mem = (uint8_t*)std::malloc(im.rgba.size() + 16);
         if (!mem) throw std::runtime_error("out of memory");
         std::memcpy(mem, im.rgba.data(), im.rgba.size());

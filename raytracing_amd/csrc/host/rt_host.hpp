@@ -12,7 +12,7 @@
 #include "../../../include/rt_core.h"
 #include "../rt_types.h"
 #include "json.h"
-#include "png.h"
+#include "jpeg.h"     // + png.h
 
 namespace rt_host {
 

@@ -9,7 +9,7 @@ from . import _lib
 from .core import RtError
 
 HOST_EXPORTS = ["rth_last_error", "rth_load_scene", "rth_load_models", "rth_scene_buffer", "rth_load_timings",
-                "rth_build_bvh", "rth_free", "rth_set_camera", "rth_orbit_camera", "rth_frame_rgba8", "rth_decode_png"]
+                "rth_build_bvh", "rth_free", "rth_set_camera", "rth_orbit_camera", "rth_frame_rgba8", "rth_decode_png", "rth_decode_image"]
 
 _bound = False
 
@@ -39,8 +39,9 @@ def _L():
         lib.rth_orbit_camera.argtypes = [i32, C.POINTER(f), C.POINTER(f)]
         lib.rth_frame_rgba8.restype = i32
         lib.rth_frame_rgba8.argtypes = [vp, u32, u32, vp]
-        lib.rth_decode_png.restype = i32
-        lib.rth_decode_png.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
+        for f in (lib.rth_decode_png, lib.rth_decode_image):
+            f.restype = i32
+            f.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
         _bound = True
     return lib
 
@@ -129,9 +130,13 @@ def frame_rgba8(cs):
     return out
 
 
-def decode_png(path):
+def decode_image(path):
+    """A texture file (PNG or JPEG) as the loader uploads it: [H, W, 4] uint8 (Texture.cpp:5-34)."""
     p, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
-    _chk(_L().rth_decode_png(str(path).encode(), C.byref(p), C.byref(w), C.byref(h)))
+    _chk(_L().rth_decode_image(str(path).encode(), C.byref(p), C.byref(w), C.byref(h)))
     a = np.frombuffer(C.string_at(p.value, w.value * h.value * 4), np.uint8).reshape(h.value, w.value, 4).copy()
     _L().rth_free(p)
     return a
+
+
+decode_png = decode_image

@@ -1,6 +1,7 @@
 // Host-side sanitizer run of the loader / BVH builder / PNG decoder (no GPU needed: ctx == NULL is the loader's dry run).
 // Build and run: tools/sanitize/run.sh   (g++ -fsanitize=address,undefined on csrc/host/rt_host.cpp; the rt_* core entry
 // points the host layer links against are answered by "no device" stand-ins below; a dry run never calls them).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -103,6 +104,45 @@ int main(int argc, char** argv) {
             EXPECT(rth_decode_png(tmp, &px, &w, &h) != RT_OK);
             rth_free(px);
         }
+        std::remove(tmp);
+    }
+    if (const char* dir = std::getenv("RT_SANITIZE_TEXTURES")) {
+        // Texture decoders on files the test wrote (t0 .. tN: JPEG baseline / progressive / restart markers / grey, PNG
+        // interlaced / 16-bit / palette): each whole, then cut short at many lengths and with bytes flipped at many
+        // places — any outcome but a memory error or undefined behaviour.
+        const char* tmp = "/tmp/rt_asan_tex.bin";
+        int files = 0;
+        for (int i = 0;; i++) {
+            const std::string src = std::string(dir) + "/t" + std::to_string(i);
+            FILE* f = std::fopen(src.c_str(), "rb");
+            if (!f) break;
+            std::vector<uint8_t> bytes;
+            { uint8_t buf[4096]; size_t k; while ((k = std::fread(buf, 1, sizeof buf, f)) > 0) bytes.insert(bytes.end(), buf, buf + k); std::fclose(f); }
+            files++;
+            uint8_t* px = nullptr; uint32_t w = 0, h = 0;
+            EXPECT(rth_decode_image(src.c_str(), &px, &w, &h) == RT_OK && w > 0 && h > 0);
+            rth_free(px);
+            auto attempt = [&](const std::vector<uint8_t>& v, size_t n) {
+                FILE* o = std::fopen(tmp, "wb"); std::fwrite(v.data(), 1, n, o); std::fclose(o);
+                uint8_t* q = nullptr; uint32_t ww = 0, hh = 0;
+                (void)rth_decode_image(tmp, &q, &ww, &hh);
+                rth_free(q);
+            };
+            for (size_t cut = 0; cut < bytes.size(); cut += 1 + bytes.size() / 61) attempt(bytes, cut);
+            uint32_t x = 12345u + (uint32_t)i;
+            for (int round = 0; round < 120; round++) {
+                std::vector<uint8_t> bad = bytes;
+                const int flips = 1 + round % 4;
+                for (int k = 0; k < flips; k++) {
+                    x = x * 1664525u + 1013904223u;
+                    // half of the damage goes to the headers (first 700 bytes: tables, frame and scan headers)
+                    const size_t span = (round & 1) ? std::min<size_t>(bad.size(), 700) : bad.size();
+                    bad[(x >> 8) % span] ^= (uint8_t)(1u << ((x >> 3) & 7));
+                }
+                attempt(bad, bad.size());
+            }
+        }
+        EXPECT(files > 0);
         std::remove(tmp);
     }
     {   // the core's compaction of uploaded buffers: a good scene, then inconsistent ones (errors, never memory errors)
