@@ -222,16 +222,23 @@ struct Builder {
         if (depth > 4096) throw std::runtime_error("BVH build: degenerate input (the reference recurses without bound here)");
         std::vector<uint32_t> order[3];
         AxisResult r[3];
+        const bool timed = build_times().on && depth <= 4;
+        const auto tn0 = std::chrono::steady_clock::now();
         auto doAxis = [&](int a) {
             if (distinct[a]) order[a] = std::move(pre[a]);
             else {
                 PhaseTimer pt(build_times().sortNs);
                 std::vector<KeyId> sorted(n);
                 const float* cen = S.cen[a].data();
-                for (size_t i = 0; i < n; i++) { sorted[i].key = cen[ids[i]]; sorted[i].id = ids[i]; }
+                // (the gathers of the few huge nodes at the top run in chunks on the free workers, like their sorts)
+                const size_t gchunks = (n >= ((size_t)1 << 20) && !serialSweeps) ? 16 : 1;
+                const uint32_t* idp = ids.data();
+                KeyId* sp = sorted.data();
+                parallelChunks(n, gchunks, [&](size_t, size_t b, size_t e) { for (size_t i = b; i < e; i++) { sp[i].key = cen[idp[i]]; sp[i].id = idp[i]; } });
                 stdSortPar(sorted.begin(), sorted.end(), [](const KeyId& x, const KeyId& y) { return x.key < y.key; });
                 order[a].resize(n);
-                for (size_t i = 0; i < n; i++) order[a][i] = sorted[i].id;
+                uint32_t* op = order[a].data();
+                parallelChunks(n, gchunks, [&](size_t, size_t b, size_t e) { for (size_t i = b; i < e; i++) op[i] = sp[i].id; });
             }
             r[a] = sweepSorted(order[a].data(), n);
         };
@@ -244,6 +251,7 @@ struct Builder {
         } else {
             for (int a = 0; a < 3; a++) doAxis(a);
         }
+        const auto tn1 = std::chrono::steady_clock::now();
         float best = r[0].cost; int axis = 0, split = r[0].index;
         if (r[1].cost < best) { best = r[1].cost; axis = 1; split = r[1].index; }
         if (r[2].cost < best) { best = r[2].cost; axis = 2; split = r[2].index; }
@@ -266,6 +274,11 @@ struct Builder {
         }
         for (int a = 0; a < 3; a++) std::vector<uint32_t>().swap(order[a]);
         std::vector<uint32_t>().swap(ids);
+        if (timed) {
+            const auto tn2 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[bvh] depth %d, %zu triangles: sorts + sweeps %.3f s, split %.3f s (axis %d at %d)\n", depth, n,
+                         std::chrono::duration<double>(tn1 - tn0).count(), std::chrono::duration<double>(tn2 - tn1).count(), axis, split);
+        }
         std::unique_ptr<Node> left, right;
         if (n >= 4096 && tryAcquire(1)) {
             auto lf = std::async(std::launch::async, [&] { return build(std::move(ids0), pre0, depth + 1); });
