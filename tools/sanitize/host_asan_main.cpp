@@ -156,6 +156,24 @@ int main(int argc, char** argv) {
         };
         const std::vector<uint8_t> nodes((const uint8_t*)b[3], (const uint8_t*)b[3] + nb[3]), tris((const uint8_t*)b[4], (const uint8_t*)b[4] + nb[4]);
         EXPECT(run(nodes, tris).empty());
+        {   // the two-level view of the same tree (knob wideNodes): derived for a tree with nested boxes, refused otherwise
+            rt::CompactScene cs;
+            EXPECT(rt::compact_scene((const rt::RefVertex*)b[0], nb[0] / 80, (const rt::RefMat4*)b[1], nb[1] / 64, nb[2] / 80,
+                                     (const rt::RefNode*)nodes.data(), nodes.size() / 48, (const rt::RefTriangle*)tris.data(), tris.size() / 128, cs).empty());
+            EXPECT(rt::derive_wide(cs) && !cs.wnodes.empty() && cs.wideDepth > 0 && 3 * cs.wideDepth + 1 <= 64);
+            size_t leaves = 0, tri = 0;
+            for (const rt::WNode& w : cs.wnodes)
+                for (int k = 0; k < 4; k++) {
+                    if (w.ref[k] >= 0) EXPECT((size_t)w.ref[k] < cs.wnodes.size());
+                    else if (w.ref[k] != -1) { leaves++; tri += (size_t)((-w.ref[k] - 1) & 7); }
+                }
+            EXPECT(tri == cs.tris.size() && leaves > 0);          // every leaf of the binary tree hangs off exactly one slot
+            if (cs.nodes.size() > 8) {
+                for (int k = 0; k < 3; k++) { cs.nodes[5].lo0[k] -= 100.f; cs.nodes[5].hi0[k] += 100.f; cs.nodes[5].lo1[k] -= 100.f; cs.nodes[5].hi1[k] += 100.f; }
+                const bool ok = rt::derive_wide(cs);             // boxes of node 5's children now stick out of their parents'
+                EXPECT(ok == !cs.wnodes.empty());
+            }
+        }
         auto node = [](std::vector<uint8_t>& v, size_t i) { return (rt::RefNode*)(v.data() + 48 * i); };
         { auto n2 = nodes; node(n2, 0)->children[1] = 0; EXPECT(!run(n2, tris).empty()); }                       // cycle
         { auto n2 = nodes; node(n2, 0)->children[0] = (int32_t)(nodes.size() / 48); EXPECT(!run(n2, tris).empty()); }   // child out of range
