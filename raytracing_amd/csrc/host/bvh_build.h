@@ -32,6 +32,7 @@
 #include <stdexcept>
 #include <thread>
 #include <vector>
+#include <sys/resource.h>
 #include "../rt_types.h"
 
 namespace rt_host {
@@ -78,13 +79,20 @@ struct GpuSweep {
 inline GpuSweep& gpu_sweep() { static GpuSweep g; return g; }
 
 // RT_BVH_TIMING=1: thread-time spent per phase (nanoseconds, summed over threads) and the wall time of the levels
-struct BuildTimes { std::atomic<long long> sortNs{0}, gatherNs{0}, sweepNs{0}, gpuNs{0}, splitNs{0}; bool on = false; };
+struct BuildTimes { std::atomic<long long> sortNs{0}, gatherNs{0}, sweepNs{0}, gpuNs{0}, splitNs{0}, leafNs{0}, waitNs{0}; bool on = false; };
 inline BuildTimes& build_times() { static BuildTimes t; return t; }
 struct PhaseTimer {
     std::atomic<long long>* acc; std::chrono::steady_clock::time_point t0;
     explicit PhaseTimer(std::atomic<long long>& a) : acc(build_times().on ? &a : nullptr) { if (acc) t0 = std::chrono::steady_clock::now(); }
     ~PhaseTimer() { if (acc) acc->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()); }
 };
+
+// Per-thread scratch of the sorts and sweeps.  A node's temporaries used to be fresh vectors: above 128 KB each of them is
+// an mmap / page-fault / munmap round trip, and with 16 threads doing that for every node the kernel's address-space lock
+// became the builder's bottleneck (thread time 44 s, wall 5.6 s at 20 M triangles).  Grow-only, released at the end of
+// build_bvh on the calling thread and at thread exit on the workers.
+struct Scratch { std::vector<KeyId> sorted; std::vector<B6> b, suf; };
+inline Scratch& scratch() { static thread_local Scratch s; return s; }
 
 struct Builder {
     const Soa& S;
@@ -100,6 +108,14 @@ struct Builder {
         return false;
     }
     void release(int k) { freeWorkers.fetch_add(k); }
+    // A thread that blocks on its helpers lends its own slot out for that time (the budget may dip below zero for a moment
+    // when it resumes; tryAcquire then fails until the balance is back).  Without this up to half of the threads sat in
+    // future::get() holding a slot: 3.9 of 8 cores busy on a 2 M-triangle build.
+    struct Lend {
+        Builder& b;
+        explicit Lend(Builder& bb) : b(bb) { b.freeWorkers.fetch_add(1); }
+        ~Lend() { b.freeWorkers.fetch_sub(1); }
+    };
 
     // f(chunkIndex, begin, end) over [0, n) in `chunks` pieces, on as many threads as the budget allows
     template <typename F>
@@ -113,7 +129,7 @@ struct Builder {
             if (e < n && tryAcquire(1)) kids.push_back(std::async(std::launch::async, [this, &f, c, b, e] { f(c, b, e); release(1); }));
             else f(c, b, e);
         }
-        for (auto& k : kids) k.get();
+        if (!kids.empty()) { Lend lend(*this); for (auto& k : kids) k.get(); }
     }
 
     // std::sort(first, last, comp) — the very permutation, tie order included — with the work spread over threads.
@@ -137,7 +153,7 @@ struct Builder {
             else introsortPar(cut, last, depth, comp);
             last = cut;
         }
-        for (auto& k : kids) k.get();
+        if (!kids.empty()) { Lend lend(*this); for (auto& k : kids) k.get(); }
     }
     template <typename It, typename Less>
     void stdSortPar(It first, It last, Less less) {
@@ -162,7 +178,10 @@ struct Builder {
             if (gpu_sweep().sweep(ids, n, &r.cost, &r.index)) return r;
         }
         PhaseTimer pt(build_times().sweepNs);
-        std::vector<B6> b(n), suf(n);
+        Scratch& scr = scratch();
+        if (scr.b.size() < n) { scr.b.resize(n); scr.suf.resize(n); }
+        B6* const b = scr.b.data();
+        B6* const suf = scr.suf.data();
         const size_t chunks = (n >= ((size_t)1 << 17) && freeWorkers.load() >= 0 && !serialSweeps) ? std::min<size_t>(64, n >> 15) : 1;
         const size_t per = (n + chunks - 1) / chunks;
         std::vector<B6> total(chunks);
@@ -202,6 +221,7 @@ struct Builder {
     bool serialSweeps = false;
 
     std::unique_ptr<Node> makeLeaf(const uint32_t* ids, size_t n) const {   // model.h:94-108
+        PhaseTimer pt(build_times().leafNs);
         auto nd = std::make_unique<Node>();
         nd->leaf = true; nd->ntri = (uint32_t)n;
         nd->lo = {FLT_MAX, FLT_MAX, FLT_MAX}; nd->hi = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -228,14 +248,15 @@ struct Builder {
             if (distinct[a]) order[a] = std::move(pre[a]);
             else {
                 PhaseTimer pt(build_times().sortNs);
-                std::vector<KeyId> sorted(n);
+                std::vector<KeyId>& sorted = scratch().sorted;
+                if (sorted.size() < n) sorted.resize(n);
                 const float* cen = S.cen[a].data();
                 // (the gathers of the few huge nodes at the top run in chunks on the free workers, like their sorts)
                 const size_t gchunks = (n >= ((size_t)1 << 20) && !serialSweeps) ? 16 : 1;
                 const uint32_t* idp = ids.data();
                 KeyId* sp = sorted.data();
                 parallelChunks(n, gchunks, [&](size_t, size_t b, size_t e) { for (size_t i = b; i < e; i++) { sp[i].key = cen[idp[i]]; sp[i].id = idp[i]; } });
-                stdSortPar(sorted.begin(), sorted.end(), [](const KeyId& x, const KeyId& y) { return x.key < y.key; });
+                stdSortPar(sorted.begin(), sorted.begin() + (ptrdiff_t)n, [](const KeyId& x, const KeyId& y) { return x.key < y.key; });
                 order[a].resize(n);
                 uint32_t* op = order[a].data();
                 parallelChunks(n, gchunks, [&](size_t, size_t b, size_t e) { for (size_t i = b; i < e; i++) op[i] = sp[i].id; });
@@ -246,7 +267,7 @@ struct Builder {
             auto f0 = std::async(std::launch::async, [&] { doAxis(0); });
             auto f1 = std::async(std::launch::async, [&] { doAxis(1); });
             try { doAxis(2); } catch (...) { f0.wait(); f1.wait(); release(2); throw; }
-            f0.get(); f1.get();
+            { PhaseTimer pw(build_times().waitNs); Lend lend(*this); f0.get(); f1.get(); }
             release(2);
         } else {
             for (int a = 0; a < 3; a++) doAxis(a);
@@ -256,6 +277,7 @@ struct Builder {
         if (r[1].cost < best) { best = r[1].cost; axis = 1; split = r[1].index; }
         if (r[2].cost < best) { best = r[2].cost; axis = 2; split = r[2].index; }
         if (split == 0) throw std::runtime_error("BVH build: SAH split at index 0 (identical bounds); the reference recurses without bound on this input");
+        std::unique_ptr<PhaseTimer> splitTimer(new PhaseTimer(build_times().splitNs));
         std::vector<uint32_t> ids0(order[axis].begin(), order[axis].begin() + split), ids1(order[axis].begin() + split, order[axis].end());
         // the children's orders on the axes with distinct keys: the winning axis' is the two halves themselves, another
         // axis' is a stable split of this node's order by the side each triangle went to
@@ -274,6 +296,7 @@ struct Builder {
         }
         for (int a = 0; a < 3; a++) std::vector<uint32_t>().swap(order[a]);
         std::vector<uint32_t>().swap(ids);
+        splitTimer.reset();
         if (timed) {
             const auto tn2 = std::chrono::steady_clock::now();
             std::fprintf(stderr, "[bvh] depth %d, %zu triangles: sorts + sweeps %.3f s, split %.3f s (axis %d at %d)\n", depth, n,
@@ -283,7 +306,7 @@ struct Builder {
         if (n >= 4096 && tryAcquire(1)) {
             auto lf = std::async(std::launch::async, [&] { return build(std::move(ids0), pre0, depth + 1); });
             try { right = build(std::move(ids1), pre1, depth + 1); } catch (...) { lf.wait(); release(1); throw; }
-            left = lf.get();
+            { PhaseTimer pw(build_times().waitNs); Lend lend(*this); left = lf.get(); }
             release(1);
         } else {
             left = build(std::move(ids0), pre0, depth + 1);
@@ -348,8 +371,11 @@ inline std::vector<RefNode> build_bvh(const RefTriangle* tris, size_t n, int wor
     if (workers <= 0) workers = default_workers();
     BuildTimes& BT = build_times();
     BT.on = std::getenv("RT_BVH_TIMING") != nullptr;
-    BT.sortNs = 0; BT.gatherNs = 0; BT.sweepNs = 0; BT.gpuNs = 0; BT.splitNs = 0;
+    BT.sortNs = 0; BT.gatherNs = 0; BT.sweepNs = 0; BT.gpuNs = 0; BT.splitNs = 0; BT.leafNs = 0; BT.waitNs = 0;
     const auto wall0 = std::chrono::steady_clock::now();
+    auto cpuNow = [] { rusage u; getrusage(RUSAGE_SELF, &u); return (double)u.ru_utime.tv_sec + u.ru_utime.tv_usec * 1e-6 + (double)u.ru_stime.tv_sec + u.ru_stime.tv_usec * 1e-6; };
+    auto sysNow = [] { rusage u; getrusage(RUSAGE_SELF, &u); return (double)u.ru_stime.tv_sec + u.ru_stime.tv_usec * 1e-6; };
+    const double cpu0 = cpuNow(), sys0 = sysNow();
     auto wall = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(); };
     double tSetup = 0, tProbe = 0, tBuild = 0, tFlat = 0;
     Builder B(S, workers - 1);
@@ -411,14 +437,15 @@ inline std::vector<RefNode> build_bvh(const RefTriangle* tris, size_t n, int wor
     try { root = B.build(std::move(ids), pre, 0); }
     catch (...) { if (B.useGpu && G.end) G.end(); throw; }
     if (B.useGpu && G.end) G.end();
+    { Scratch& scr = scratch(); std::vector<KeyId>().swap(scr.sorted); std::vector<B6>().swap(scr.b); std::vector<B6>().swap(scr.suf); }
     tBuild = wall();
     std::vector<RefNode> out;
     out.reserve(n);
     flatten(root.get(), out);
     tFlat = wall();
     if (BT.on)
-        std::fprintf(stderr, "[bvh] %zu triangles, %d workers, gpu sweeps %d: wall setup %.3f probe %.3f build %.3f flatten %.3f s; thread time sort %.3f host sweep %.3f gpu sweep %.3f s\n",
-                     n, workers, (int)B.useGpu, tSetup, tProbe - tSetup, tBuild - tProbe, tFlat - tBuild, BT.sortNs.load() * 1e-9, BT.sweepNs.load() * 1e-9, BT.gpuNs.load() * 1e-9);
+        std::fprintf(stderr, "[bvh] %zu triangles, %d workers, gpu sweeps %d: wall setup %.3f probe %.3f build %.3f flatten %.3f s; thread time sort %.3f host sweep %.3f gpu sweep %.3f split %.3f leaves %.3f waiting for a sibling %.3f s; process CPU time %.3f s (system %.3f)\n",
+                     n, workers, (int)B.useGpu, tSetup, tProbe - tSetup, tBuild - tProbe, tFlat - tBuild, BT.sortNs.load() * 1e-9, BT.sweepNs.load() * 1e-9, BT.gpuNs.load() * 1e-9, BT.splitNs.load() * 1e-9, BT.leafNs.load() * 1e-9, BT.waitNs.load() * 1e-9, cpuNow() - cpu0, sysNow() - sys0);
     // deep trees: release iteratively to keep the destructor recursion shallow
     std::vector<std::unique_ptr<Node>> pend;
     pend.push_back(std::move(root));
