@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -16,12 +17,46 @@
 
 namespace rt {
 
+// An array that is not value-initialised when it is sized: the big per-triangle tables are written in full by several
+// threads, and zero-filling gigabytes on one thread first (std::vector::resize) took longer than filling them.
+template <typename T>
+struct RawBuf {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void alloc(size_t k) { p.reset(k ? new T[k] : nullptr); n = k; }
+    void clear() { p.reset(); n = 0; }
+    T* data() { return p.get(); }
+    const T* data() const { return p.get(); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
+// f(lo, hi, chunk) over [0, n) on up to 32 threads (the job's CPU share when OMP_NUM_THREADS states one); one thread below `serialBelow`
+template <typename F>
+static inline unsigned parallel_ranges(uint64_t n, uint64_t serialBelow, F f) {
+    unsigned nThreads = 1;
+    if (n >= serialBelow) {
+        nThreads = std::thread::hardware_concurrency();
+        if (const char* e = std::getenv("OMP_NUM_THREADS")) { int v = std::atoi(e); if (v > 0 && (unsigned)v < nThreads) nThreads = (unsigned)v; }
+        nThreads = std::max(1u, std::min(nThreads, 32u));
+    }
+    const uint64_t per = (n + nThreads - 1) / nThreads;
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < nThreads; k++) th.emplace_back(f, std::min<uint64_t>(n, k * per), std::min<uint64_t>(n, (k + 1) * per), k);
+    f(0, std::min<uint64_t>(n, per), 0u);
+    for (auto& t : th) t.join();
+    return nThreads;
+}
+
 struct CompactScene {
     std::vector<CNode> nodes;
     std::vector<WNode> wnodes;      // two-level view of `nodes` (empty when the tree does not allow it, see derive_wide)
-    std::vector<CTri> tris;
-    std::vector<CShade> shade;
-    std::vector<CShadeUV> shadeUV;
+    std::vector<CTri> tris;         // (released after the upload: nTris keeps the count)
+    RawBuf<CShade> shade;
+    RawBuf<CShadeUV> shadeUV;       // filled by fill_shade_uv, only for scenes with a textured material
+    uint64_t nTris = 0;
     int32_t rootChild = -1;
     float rootLo[3] = {0, 0, 0}, rootHi[3] = {0, 0, 0};
     float sceneScale = 1.f;
@@ -46,63 +81,55 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
     if (nNodes == 0) return "BVH node buffer (slot 3) is empty";
     if (nTris >= (1ull << 28)) return "too many triangles for the leaf encoding";
     // ---- per-triangle world-space vertices + shading records (independent per triangle: spread over threads) ----
-    std::vector<f3> wv(nTris * 3);
-    out.shade.resize(nTris);
-    out.shadeUV.resize(nTris);
-    auto perTriangle = [&](uint64_t lo, uint64_t hi, std::string* err, uint64_t* errAt) {
-        for (uint64_t i = lo; i < hi; i++) {
-            const RefTriangle& t = rtris[i];
-            const char* bad = nullptr;
-            for (int k = 0; k < 3 && !bad; k++)
-                if (t.indices[k] >= nVerts) bad = ": vertex index out of range";
-            if (!bad && t.meshIndex >= nMats) bad = ": meshIndex out of range";
-            if (!bad && t.materialIndex >= nMaterials) bad = ": materialIndex out of range";
-            if (bad) { *err = "triangle " + std::to_string(i) + bad; *errAt = i; return; }
-            const RefMat4& M = mats[t.meshIndex];
-            for (int k = 0; k < 3; k++) wv[i * 3 + k] = mul_point(M, verts[t.indices[k]].position, 1.f);
-            CShade& s = out.shade[i];
-            CShadeUV& su = out.shadeUV[i];
-            std::memset(&su, 0, sizeof su);
-            s.pad = 0;
-            const f3 P[3] = {t.p1, t.p2, t.p3};
-            float* dstP[3] = {s.a, s.b, s.c};
-            float* dstN[3] = {s.n1, s.n2, s.n3};
-            float* dstUV[3] = {su.uv1, su.uv2, su.uv3};
-            for (int k = 0; k < 3; k++) {
-                dstP[k][0] = P[k].x; dstP[k][1] = P[k].y; dstP[k][2] = P[k].z;
-                f3 n = mul_point(M, verts[t.indices[k]].normal, 0.f);
-                dstN[k][0] = n.x; dstN[k][1] = n.y; dstN[k][2] = n.z;
-                dstUV[k][0] = verts[t.indices[k]].texUV[0]; dstUV[k][1] = verts[t.indices[k]].texUV[1];
-            }
-            s.materialIndex = t.materialIndex;
-            su.i1 = t.indices[0]; su.i2 = t.indices[1]; su.i3 = t.indices[2];
-        }
-    };
+    RawBuf<f3> wv;
+    wv.alloc(nTris * 3);
+    std::vector<float> sceneMaxAbs;
+    out.shade.alloc(nTris);
+    out.shadeUV.clear();
+    out.nTris = nTris;
     {
-        unsigned nThreads = 1;
-        if (nTris >= (1u << 18)) {
-            nThreads = std::thread::hardware_concurrency();
-            if (const char* e = std::getenv("OMP_NUM_THREADS")) { int v = std::atoi(e); if (v > 0 && (unsigned)v < nThreads) nThreads = (unsigned)v; }
-            nThreads = std::max(1u, std::min(nThreads, 32u));
-        }
-        std::vector<std::string> errs(nThreads);
-        std::vector<uint64_t> errAt(nThreads, ~0ull);
-        std::vector<std::thread> th;
-        const uint64_t per = (nTris + nThreads - 1) / nThreads;
-        for (unsigned k = 1; k < nThreads; k++)
-            th.emplace_back(perTriangle, std::min<uint64_t>(nTris, k * per), std::min<uint64_t>(nTris, (k + 1) * per), &errs[k], &errAt[k]);
-        perTriangle(0, std::min<uint64_t>(nTris, per), &errs[0], &errAt[0]);
-        for (auto& t : th) t.join();
+        std::vector<std::string> errs(32);
+        std::vector<uint64_t> errAt(32, ~0ull);
+        std::vector<float> maxAbs(32, 0.f);
+        const unsigned nThreads = parallel_ranges(nTris, 1u << 18, [&](uint64_t lo, uint64_t hi, unsigned k) {
+            float m = 0.f;
+            for (uint64_t i = lo; i < hi; i++) {
+                const RefTriangle& t = rtris[i];
+                const char* bad = nullptr;
+                for (int v = 0; v < 3 && !bad; v++)
+                    if (t.indices[v] >= nVerts) bad = ": vertex index out of range";
+                if (!bad && t.meshIndex >= nMats) bad = ": meshIndex out of range";
+                if (!bad && t.materialIndex >= nMaterials) bad = ": materialIndex out of range";
+                if (bad) { errs[k] = "triangle " + std::to_string(i) + bad; errAt[k] = i; return; }
+                const RefMat4& M = mats[t.meshIndex];
+                for (int v = 0; v < 3; v++) {
+                    const f3 w = mul_point(M, verts[t.indices[v]].position, 1.f);
+                    wv[i * 3 + v] = w;
+                    m = std::max(m, std::fabs(w.x)); m = std::max(m, std::fabs(w.y)); m = std::max(m, std::fabs(w.z));      // (a NaN never replaces m)
+                }
+                CShade& s = out.shade[i];
+                s.pad = 0;
+                const f3 P[3] = {t.p1, t.p2, t.p3};
+                float* dstP[3] = {s.a, s.b, s.c};
+                float* dstN[3] = {s.n1, s.n2, s.n3};
+                for (int v = 0; v < 3; v++) {
+                    dstP[v][0] = P[v].x; dstP[v][1] = P[v].y; dstP[v][2] = P[v].z;
+                    f3 n = mul_point(M, verts[t.indices[v]].normal, 0.f);
+                    dstN[v][0] = n.x; dstN[v][1] = n.y; dstN[v][2] = n.z;
+                }
+                s.materialIndex = t.materialIndex;
+            }
+            maxAbs[k] = m;
+        });
         unsigned first = nThreads;                       // the error of the lowest triangle index, as the sequential loop reports it
         for (unsigned k = 0; k < nThreads; k++) if (!errs[k].empty() && (first == nThreads || errAt[k] < errAt[first])) first = k;
         if (first != nThreads) return errs[first];
+        sceneMaxAbs = maxAbs;
     }
 
     // ---- scene scale (for the slack terms of traversalMode 0) ----
     float scale = 0.f;
-    for (uint64_t i = 0; i < nTris * 3; i++) {
-        scale = std::max(scale, std::fabs(wv[i].x)); scale = std::max(scale, std::fabs(wv[i].y)); scale = std::max(scale, std::fabs(wv[i].z));
-    }
+    for (float m : sceneMaxAbs) scale = std::max(scale, m);
     if (!(scale > 0.f) || !std::isfinite(scale)) scale = 1.f;
     out.sceneScale = scale;
     const float padAbs = 1e-5f * scale;
@@ -247,6 +274,23 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
         out.rootChild = 0;
     }
     return "";
+}
+
+// The texture-coordinate / vertex-id records (CShadeUV) of a scene that compact_scene accepted (its index checks hold):
+// only k_shade's textured and normal-mapped materials read them, so scenes without such a material never build or upload
+// this table (config 4: 960 MB).
+static inline void fill_shade_uv(const RefVertex* verts, const RefTriangle* rtris, uint64_t nTris, CompactScene& out) {
+    out.shadeUV.alloc(nTris);
+    parallel_ranges(nTris, 1u << 18, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t i = lo; i < hi; i++) {
+            const RefTriangle& t = rtris[i];
+            CShadeUV& su = out.shadeUV[i];
+            std::memset(&su, 0, sizeof su);
+            float* dstUV[3] = {su.uv1, su.uv2, su.uv3};
+            for (int v = 0; v < 3; v++) { dstUV[v][0] = verts[t.indices[v]].texUV[0]; dstUV[v][1] = verts[t.indices[v]].texUV[1]; }
+            su.i1 = t.indices[0]; su.i2 = t.indices[1]; su.i3 = t.indices[2];
+        }
+    });
 }
 
 // The two-level nodes (WNode) of a compacted tree, numbered breadth-first like the binary ones.  Returns false — and

@@ -49,7 +49,20 @@ struct rt_ctx {
     std::string err;
 
     // host copies of the reference buffers (slot uploads copy immediately; compaction is lazy)
-    std::vector<uint8_t> slotHost[6];
+    // The six uploaded buffers as the caller handed them over (rt_upload_buffer copies at once, as glBufferData does).
+    // Copied by several threads when large: the first touch of gigabytes of fresh pages by one thread cost 1.5 s at config 4.
+    struct HostBuf {
+        std::unique_ptr<uint8_t[]> p; size_t n = 0, cap = 0;
+        const uint8_t* data() const { return p.get(); }
+        size_t size() const { return n; }
+        void assign(const uint8_t* src, size_t bytes) {
+            if (bytes > cap || bytes < cap / 2) { p.reset(bytes ? new uint8_t[bytes] : nullptr); cap = bytes; }
+            n = bytes;
+            uint8_t* dst = p.get();
+            rt::parallel_ranges(bytes, (uint64_t)64 << 20, [&](uint64_t lo, uint64_t hi, unsigned) { if (hi > lo) std::memcpy(dst + lo, src + lo, hi - lo); });
+        }
+    };
+    HostBuf slotHost[6];
     bool slotSet[6] = {false, false, false, false, false, false};
     bool sceneDirty = true, lightsDirty = true, materialsDirty = true, texturesDirty = true;
 
@@ -99,7 +112,8 @@ struct rt_ctx {
     int32_t sunKernel = 1;      // 0: the general k_shadow also for one-sun scenes (A/B knob)
     // wideNodes != 0: the refill kernels walk two-level nodes (WNode) derived from the same tree, when it qualifies (derive_wide)
     int32_t wideNodes = 0;
-    bool wideReady = false;     // derive_wide has run for the scene on the device (its result may be "does not qualify")
+    bool wideReady = false;
+    bool uvReady = false;       // the CShadeUV table of the scene on the device has been built (it is only when a material is textured)     // derive_wide has run for the scene on the device (its result may be "does not qualify")
     bool anyTextured = true, anyTransmissive = true;   // which k_shade variant the scene needs (set with the materials)
     uint32_t nslotsAlloc = 0, pendLights = 0, countersAlloc = 0;
 
@@ -156,9 +170,12 @@ rt_status sync_scene(rt_ctx* c) {
         if ((s = upload(c, c->dNodes, c->cs.nodes.data(), c->cs.nodes.size() * sizeof(CNode)))) return s;
         if ((s = upload(c, c->dTris, c->cs.tris.data(), c->cs.tris.size() * sizeof(CTri)))) return s;
         if ((s = upload(c, c->dShade, c->cs.shade.data(), c->cs.shade.size() * sizeof(CShade)))) return s;
-        if ((s = upload(c, c->dShadeUV, c->cs.shadeUV.data(), c->cs.shadeUV.size() * sizeof(CShadeUV)))) return s;
         if ((s = upload(c, c->dVertices, V.data(), V.size()))) return s;
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        // the device has them now: the host keeps the node arrays (two-level derivation) and the counts
+        c->cs.shade.clear(); c->cs.shadeUV.clear();
+        std::vector<CTri>().swap(c->cs.tris);
+        c->uvReady = false;
         c->sceneDirty = false;
         c->tuneState = 0; c->tuneChoice = 0;
         c->wideReady = false; c->cs.wnodes.clear(); c->cs.wideDepth = 0;
@@ -198,6 +215,16 @@ rt_status sync_scene(rt_ctx* c) {
         if ((s = upload(c, c->dCMat, cm.data(), cm.size() * sizeof(CMat)))) return s;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->materialsDirty = false;
+    }
+    if (c->anyTextured && !c->uvReady) {
+        // texture coordinates and vertex ids per triangle: only textured / normal-mapped materials read them
+        const auto& V = c->slotHost[RT_SLOT_VERTICES]; const auto& T = c->slotHost[RT_SLOT_TRIANGLES];
+        fill_shade_uv((const RefVertex*)V.data(), (const RefTriangle*)T.data(), T.size() / 128, c->cs);
+        rt_status s = upload(c, c->dShadeUV, c->cs.shadeUV.data(), c->cs.shadeUV.size() * sizeof(CShadeUV));
+        if (s) return s;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->cs.shadeUV.clear();
+        c->uvReady = true;
     }
     if (c->lightsDirty) {
         const auto& L = c->slotHost[RT_SLOT_LIGHTS];
@@ -420,7 +447,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     k_init_frame<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, iAlb, iNor, iDep);
 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
-    const size_t bvhBytes = c->cs.nodes.size() * sizeof(CNode) + c->cs.tris.size() * sizeof(CTri);
+    const size_t bvhBytes = c->cs.nodes.size() * sizeof(CNode) + (size_t)c->cs.nTris * sizeof(CTri);
     const bool bigScene = bvhBytes > (size_t)64 << 20;
     // Which traversal kernels: bit 0 = refill kernel for closest-hit rays, bit 1 = for shadow rays.
     static const int kTuneTrial[4] = {0, 3, 1, 2};
@@ -745,7 +772,7 @@ rt_status rt_upload_buffer(rt_ctx* c, uint32_t slot, const void* data, uint64_t 
     if (slot > 5) return fail(c, RT_ERR_INVALID, "slot must be 0..5");
     if (bytes && !data) return fail(c, RT_ERR_INVALID, "data is NULL");
     if (bytes % kRecordSize[slot]) return fail(c, RT_ERR_INVALID, "size is not a multiple of the slot's record size");
-    c->slotHost[slot].assign((const uint8_t*)data, (const uint8_t*)data + bytes);
+    c->slotHost[slot].assign((const uint8_t*)data, (size_t)bytes);
     c->slotSet[slot] = true;
     if (slot == RT_SLOT_LIGHTS) c->lightsDirty = true;
     else if (slot == RT_SLOT_MATERIALS) { c->materialsDirty = true; c->sceneDirty = true; }
