@@ -361,6 +361,38 @@ def test_extreme_frame_shapes_agree_across_kernel_families(models_root, W, H, sp
     cs.Delete()
 
 
+def test_materials_that_gain_textures_after_the_first_frame(oracle_lib, models_root):
+    """The per-triangle texture-coordinate table is built and uploaded only once a material samples a texture: scene 3
+    first with its texture flags cleared (no table), then with the real materials bound to slot 2 alone — the second frame
+    must be the textured scene's, bit for bit, and a third upload of the plain materials the plain frame again."""
+    from raytracing_amd import ComputeShader, SSBO
+    sc = oracle_lib.load_scene(models_root, 3)
+    assert (sc.materials["hasBaseTexture"] == 1).any()
+    W, H, spp, b = 96, 64, 2, 4
+    want_tex = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
+    import copy
+    plain = copy.copy(sc)
+    plain.materials = sc.materials.copy()
+    for fld in ("hasBaseTexture", "hasNormalTexture", "hasMetallicRoughnessTexture"):
+        plain.materials[fld] = 0
+    want_plain = oracle_lib.render(plain, oracle_lib.make_params(plain, W, H, spp, b, math_mode=1))
+    assert not same_floats(want_tex["color"], want_plain["color"]).all()
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, b)                      # creates the textures, binds the textured materials ...
+    SSBO.Bind(cs, plain.materials, plain.materials.nbytes, 2)      # ... which the plain ones replace before the first frame
+    cs.dispatch()
+    assert same_floats(cs.get_image(0), want_plain["color"]).all()
+    mats = sc.materials.copy()                              # handles 1.. are the textures in creation order (setup_core)
+    SSBO.Bind(cs, mats, mats.nbytes, 2)
+    cs.dispatch()
+    for k, name in enumerate(("color", "albedo", "normal", "depth")):
+        assert same_floats(cs.get_image(k), want_tex[name]).all(), name
+    SSBO.Bind(cs, plain.materials, plain.materials.nbytes, 2)
+    cs.dispatch()
+    assert same_floats(cs.get_image(0), want_plain["color"]).all()
+    cs.Delete()
+
+
 def test_contexts_release_their_device_memory(scene4):
     """rt_destroy (ComputeShader::Delete) frees images, scene, path buffers, streams and events: free device memory after
     twelve create / render / destroy rounds is what it was after the first."""
