@@ -314,7 +314,9 @@ def main():
         # vector-memory path, >= 17 CU-cycles each however few lanes are active (tools/ubench/gather_rate.hip).  What the
         # bounce rays' closest-hit launches would cost at that floor alone, against what they took: a fraction below 1.
         if c["wave_node_steps"] and c["rays_bounce"]:
-            wave_loads = (4 * c["wave_node_steps"] + 3 * c["wave_tri_steps"]) * (ex["rays_bounce"] / c["rays_bounce"])
+            # (two-level nodes: a visit is 7 loads and is counted as two node steps)
+            loads_per_node_step = 3.5 if last_stats.get("wide_nodes") else 4
+            wave_loads = (loads_per_node_step * c["wave_node_steps"] + 3 * c["wave_tri_steps"]) * (ex["rays_bounce"] / c["rays_bounce"])
             floor_ms = wave_loads * VMEM_CYCLES_PER_WAVE_LOAD / (cus * CU_CLOCK_HZ) * 1e3
             bounce_ms = ex["ms_extend"] - ex["ms_extend_primary"]
             roofline["issue_floor"] = {"floor_ms_per_frame": round(floor_ms, 2), "measured_ms_per_frame": round(bounce_ms, 2),
@@ -339,6 +341,7 @@ def main():
                        "parallelism": "sample-range x%d, RCCL reduce of the colour buffer" % world if world > 1 else "single GPU",
                        "traversal": "culled/ordered (traversalMode 0)",
                        "traversal_kernels": KERNEL_CHOICE.get(last_stats.get("kernel_choice"), "?") +
+                                            (" on two-level nodes (128-byte records, %d steps deep)" % last_stats.get("wide_depth", 0) if last_stats.get("wide_nodes") else "") +
                                             ("" if last_stats.get("kernel_choice_settled") else " [trial not finished]")},
             "rays": {"total": rays, "primary": agg["rays_primary"], "bounce": agg["rays_bounce"], "shadow": agg["rays_shadow"],
                      "shadow_skipped": agg["rays_shadow_skipped"], "note": "rank-0 split; total is all ranks" if world > 1 else "per %d steps" % args.steps},

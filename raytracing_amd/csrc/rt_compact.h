@@ -329,7 +329,8 @@ static inline bool derive_wide(CompactScene& out) {
     }
     if (3u * out.wideDepth + 1u > 64u) { out.wideDepth = 0; return false; }       // too deep for the 64-entry stack
     out.wnodes.resize(order.size());
-    for (size_t w = 0; w < order.size(); w++) {
+    parallel_ranges(order.size(), 1u << 18, [&](uint64_t wlo, uint64_t whi, unsigned) {
+    for (size_t w = wlo; w < whi; w++) {
         WNode& W = out.wnodes[w];
         std::memset(&W, 0, sizeof W);
         int ns = 0;
@@ -360,6 +361,7 @@ static inline bool derive_wide(CompactScene& out) {
             W.ref[ns] = -1;
         }
     }
+    });
     return true;
 }
 

@@ -110,8 +110,9 @@ struct rt_ctx {
     int32_t kernelChoice = -1;  // >= 0: this combination (bit 0 / bit 1 as tuneChoice) whatever was measured: every rank of a
                                 // multi-GPU job is given rank 0's choice, so that shards cost the same everywhere
     int32_t sunKernel = 1;      // 0: the general k_shadow also for one-sun scenes (A/B knob)
-    // wideNodes != 0: the refill kernels walk two-level nodes (WNode) derived from the same tree, when it qualifies (derive_wide)
-    int32_t wideNodes = 0;
+    // The refill kernels walk two-level nodes (WNode) derived from the same tree, when it qualifies (derive_wide):
+    // 1 always, 0 never, -1 for BVHs far larger than the L2s (where they pay: config 4 -8 %)
+    int32_t wideNodes = -1;
     bool wideReady = false;
     bool uvReady = false;       // the CShadeUV table of the scene on the device has been built (it is only when a material is textured)     // derive_wide has run for the scene on the device (its result may be "does not qualify")
     bool anyTextured = true, anyTransmissive = true;   // which k_shade variant the scene needs (set with the materials)
@@ -155,6 +156,12 @@ rt_status upload(rt_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 
 const size_t kRecordSize[6] = {80, 64, 80, 48, 128, 48};
 
+// BVHs this much larger than the L2s (32 MB) are traversed out of the Infinity Cache and HBM: the refill kernels and the
+// two-level nodes are their defaults
+constexpr size_t kBigBvhBytes = (size_t)64 << 20;
+size_t bvh_bytes(const rt_ctx* c) { return c->cs.nodes.size() * sizeof(CNode) + (size_t)c->cs.nTris * sizeof(CTri); }
+bool want_wide(const rt_ctx* c) { return c->wideNodes > 0 || (c->wideNodes < 0 && bvh_bytes(c) > kBigBvhBytes); }
+
 rt_status sync_scene(rt_ctx* c) {
     for (int s = 0; s < 6; s++)
         if (!c->slotSet[s]) return fail(c, RT_ERR_NOT_READY, "slot " + std::to_string(s) + " has not been uploaded");
@@ -180,7 +187,7 @@ rt_status sync_scene(rt_ctx* c) {
         c->tuneState = 0; c->tuneChoice = 0;
         c->wideReady = false; c->cs.wnodes.clear(); c->cs.wideDepth = 0;
     }
-    if (c->wideNodes != 0 && !c->wideReady) {
+    if (want_wide(c) && !c->wideReady) {
         if (derive_wide(c->cs)) {
             rt_status s = upload(c, c->dWNodes, c->cs.wnodes.data(), c->cs.wnodes.size() * sizeof(WNode));
             if (s) return s;
@@ -257,7 +264,7 @@ SceneView make_view(rt_ctx* c, bool exact) {
     for (int k = 0; k < 3; k++) { S.rootLo[k] = c->cs.rootLo[k]; S.rootHi[k] = c->cs.rootHi[k]; }
     S.cullAbs = 1e-5f * c->cs.sceneScale;
     S.exactMode = exact ? 1 : 0;
-    S.wnodes = (!exact && c->wideNodes != 0 && c->wideReady && !c->cs.wnodes.empty()) ? (const WNode*)c->dWNodes.p : nullptr;
+    S.wnodes = (!exact && want_wide(c) && c->wideReady && !c->cs.wnodes.empty()) ? (const WNode*)c->dWNodes.p : nullptr;
     return S;
 }
 
@@ -447,8 +454,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     k_init_frame<<<pixBlocks, RT_BLOCK, 0, st>>>(F, P, iAlb, iNor, iDep);
 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
-    const size_t bvhBytes = c->cs.nodes.size() * sizeof(CNode) + (size_t)c->cs.nTris * sizeof(CTri);
-    const bool bigScene = bvhBytes > (size_t)64 << 20;
+    const bool bigScene = bvh_bytes(c) > kBigBvhBytes;
     // Which traversal kernels: bit 0 = refill kernel for closest-hit rays, bit 1 = for shadow rays.
     static const int kTuneTrial[4] = {0, 3, 1, 2};
     const int comboDefault = bigScene ? 3 : 0;      // until measured: refill where traversal is bound by miss latency

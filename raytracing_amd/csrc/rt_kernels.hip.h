@@ -217,20 +217,24 @@ __device__ __forceinline__ void test_tri(float4 A, float4 B, float4 C, int idx, 
 // from the tree depth at scene load (coalesced the same way).  No scratch memory is used.  A push beyond the
 // total capacity (>= 64 entries = shader.comp:246) is dropped like the reference's `stackPtr < 64` guard.
 struct Stack {
-    uint2* lds; volatile uint32_t* ov; uint32_t ovStride; int cap;
+    typedef unsigned long long __attribute__((address_space(1))) GlobalEntry;      // an entry of the overflow area (x low, y high), named as global memory
+    uint2* lds; GlobalEntry* ov; uint32_t ovStride; int cap;
     int ldsDepth, ldsStride;   // entries kept in LDS per lane, distance between a lane's consecutive entries (= workgroup size)
-    // The overflow accesses are volatile so that the compiler keeps them apart from the LDS accesses (merged, both
-    // become flat_* instructions on a selected pointer, which are slower than ds_* and count on two wait counters).
+    // The overflow pointer carries the global address space so that the compiler keeps these accesses apart from the LDS
+    // ones (merged through a generic pointer, both become flat_* instructions on a selected address, which are slower
+    // than ds_* and count on two wait counters) — and each entry moves as one cached 8-byte access.  (They used to be
+    // volatile dword pairs: two system-scope round trips per entry, which a tree deeper than the LDS part pays on every
+    // deep push and pop.)
     __device__ __forceinline__ void push(int& sp, uint2 e) const {
         if (sp < ldsDepth) lds[sp * ldsStride] = e;
-        else if (sp < cap) { volatile uint32_t* q = ov + (size_t)(sp - ldsDepth) * ovStride * 2u; q[0] = e.x; q[1] = e.y; }
+        else if (sp < cap) ov[(size_t)(sp - ldsDepth) * ovStride] = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
         if (sp < cap) sp++;
     }
     __device__ __forceinline__ uint2 pop(int& sp) const {
         sp--;
         if (sp < ldsDepth) return lds[sp * ldsStride];
-        volatile uint32_t* q = ov + (size_t)(sp - ldsDepth) * ovStride * 2u;
-        uint2 e; e.x = q[0]; e.y = q[1];
+        const unsigned long long v = ov[(size_t)(sp - ldsDepth) * ovStride];
+        uint2 e; e.x = (uint32_t)v; e.y = (uint32_t)(v >> 32);
         return e;
     }
 };
@@ -240,7 +244,7 @@ __device__ __forceinline__ Stack make_stack(uint2* ldsBase, const struct PathBuf
     Stack st;
     st.lds = ldsBase + threadIdx.x;
     st.ldsDepth = ldsDepth; st.ldsStride = block;
-    st.ov = reinterpret_cast<volatile uint32_t*>(P.overflow + (blockIdx.x * (uint32_t)block + threadIdx.x));
+    st.ov = (Stack::GlobalEntry*)(P.overflow + (blockIdx.x * (uint32_t)block + threadIdx.x));
     st.ovStride = P.overflowStride;
     st.cap = ldsDepth + (int)P.overflowDepth;
     return st;

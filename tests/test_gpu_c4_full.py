@@ -3,9 +3,9 @@ bench.py --workload c4 times — checked, once.  It is the only configuration wh
 Triangle records through one 32-bit-sized SSBO::Bind, 48-byte leaf codes first*8+count up to 1.6e8) and whose tree is
 deeper than the kernels' LDS stack part by ~20 levels, so the global stack overflow area carries real traffic.
 
-(i)  1920x1080, 8 bounces: the default kernels (refill for a BVH this size), the batch kernels (refill = 0), the refill
-     kernels on two-level nodes (wideNodes = 1: 21 two-level steps deep here) and the reference-order exhaustive walk
-     (traversalMode = 1) give bit-identical images (all four), primary-hit ids and ray counts.
+(i)  1920x1080, 8 bounces: the default kernels (for a BVH this size: the refill kernels on two-level nodes), the batch
+     kernels (refill = 0), the refill kernels on the binary nodes (wideNodes = 0) and the reference-order exhaustive
+     walk (traversalMode = 1) give bit-identical images (all four), primary-hit ids and ray counts.
 (ii) The oracle (oracle/rt_ref.cpp: lineCast and the full integrator, shader.comp:243-537) runs on the very buffers the
      product's loader and builder bound (rth_scene_buffer): a few thousand rt_trace_rays rays and two 12x8 windows of
      the full-size frame, bit for bit.  The oracle does not rebuild the BVH here: builder parity is pinned at small sizes
@@ -39,7 +39,7 @@ def test_c4_full_size_all_kernel_families_and_oracle_windows(oracle_lib, tmp_pat
 
     # (i) three kernel families, one answer
     runs = {}
-    for name, knobs in (("default", {}), ("batch", {"refill": 0}), ("two-level nodes", {"wideNodes": 1}), ("reference order", {"traversalMode": 1})):
+    for name, knobs in (("default", {}), ("batch", {"refill": 0}), ("binary nodes", {"wideNodes": 0}), ("reference order", {"traversalMode": 1})):
         for k, v in knobs.items():
             cs.setInt(k, v)
         cs.dispatch()
@@ -47,12 +47,13 @@ def test_c4_full_size_all_kernel_families_and_oracle_windows(oracle_lib, tmp_pat
         print("  %-16s %.0f ms, rays %d / %d / %d (+%d skipped)" % (name, st["ms_total"], st["rays_primary"], st["rays_bounce"], st["rays_shadow"], st["rays_shadow_skipped"]))
         runs[name] = ([cs.get_image(k) for k in range(4)], cs.primary_hits()[0], st)
         for k in knobs:
-            cs.setInt(k, {"refill": -1, "traversalMode": 0, "wideNodes": 0}[k])
+            cs.setInt(k, {"refill": -1, "traversalMode": 0, "wideNodes": -1}[k])
     base = runs["default"]
+    assert base[2]["wide_nodes"] == 1 and runs["binary nodes"][2]["wide_nodes"] == 0 and base[2]["wide_depth"] >= 10
     assert base[2]["rays_primary"] == W * H * SPP
     assert (base[1] >= 0).mean() > 0.3                     # the field fills the lower part of the frame
     assert int(base[1].max()) > 1 << 24                    # ids beyond what a float index could name
-    for name in ("batch", "two-level nodes", "reference order"):
+    for name in ("batch", "binary nodes", "reference order"):
         other = runs[name]
         for k in range(4):
             assert same_floats(other[0][k], base[0][k]).all(), (name, k)
