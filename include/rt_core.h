@@ -81,8 +81,8 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * are rendered with the four combinations (refill or not, for closest-hit and for shadow rays) and the fastest is kept;
  * until then BVHs far larger than the L2s use them and others do not), kernelChoice (-1 / 0..3: that combination whatever
  * was measured, reported back in rt_stats.kernel_choice; a multi-GPU job gives every rank rank 0's), fusePairs (1 / 0: the
- * shadow rays of a bounce and the closest-hit rays of the next are traced by one launch), wideNodes (0 / 1: the refill
- * kernels walk two-level nodes derived from the same tree; same images), refillIdle, refillNodeMin,
+ * shadow rays of a bounce and the closest-hit rays of the next are traced by one launch), wideNodes (-1 / 0 / 1: the refill
+ * kernels walk two-level nodes derived from the same tree, by default for BVHs far larger than the L2s; same images), refillIdle, refillNodeMin,
  * refillBlocksPerCU. */
 rt_status rt_set_int(rt_ctx* ctx, const char* name, int32_t v);
 rt_status rt_set_float(rt_ctx* ctx, const char* name, float v);
