@@ -100,9 +100,10 @@ struct rt_ctx {
     int32_t refill = -1, refillIdle = 16, refillNodeMin = 28, refillBlocksPerCU = 0;
     int32_t refillTriMin = 0, refillNodeLow = 0, refillDefer = 0;   // 0 = the kernels' defaults (rt_trace_refill.hip.h, RefillSched)   // refillBlocksPerCU 0 = automatic (refill_blocks)
     // refill = -1: which traversal kernels are faster depends on the scene, and not the same way for closest-hit and
-    // shadow rays (scene 7: closest hit +14 % with refill, one-sun shadow rays -5 %; scene 4: batch for both; the
-    // 20 M-triangle field: refill for both), so the first four sizeable frames after a scene upload are rendered with
-    // the four combinations and the fastest (rays per millisecond) is kept.  Images do not depend on the choice.
+    // shadow rays (closest hit: the refill kernel on every scene measured; shadow rays: the one-sun batch kernel and the
+    // refill kernel within a few per cent of each other on scenes 3, 4 and 7, the refill kernel by far on the
+    // 20 M-triangle field), so the first four sizeable frames after a scene upload are rendered with the four
+    // combinations and the fastest (rays per millisecond) is kept.  Images do not depend on the choice.
     uint64_t allocations = 0;   // hipMalloc calls so far (a frame that allocated is not a timing sample)
     int tuneState = 0;          // 0..3: the next sizeable frame samples combination kTuneTrial[tuneState]; 4: decided
     double tuneRate[4] = {0.0, 0.0, 0.0, 0.0};
@@ -456,10 +457,12 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const uint32_t traceBlocks = trace_blocks(c, nslots);
     const bool bigScene = bvh_bytes(c) > kBigBvhBytes;
     // Which traversal kernels: bit 0 = refill kernel for closest-hit rays, bit 1 = for shadow rays.
-    static const int kTuneTrial[4] = {0, 3, 1, 2};
-    const int comboDefault = bigScene ? 3 : 0;      // until measured: refill where traversal is bound by miss latency
+    static const int kTuneTrial[4] = {1, 3, 0, 2};
+    // until measured: the refill kernel for closest-hit rays (the faster one on every scene measured so far), and for
+    // shadow rays too where traversal is bound by miss latency
+    const int comboDefault = bigScene ? 3 : 1;
     const bool trial = !exact && !count && c->refill < 0 && c->kernelChoice < 0 && c->tuneState < 4 &&
-                       (double)w * (double)h * (double)(r1 - r0) >= 2.5e7;      // a frame large enough to be a measurement
+                       (double)w * (double)h * (double)(r1 - r0) >= 1.0e7;      // a frame large enough to be a measurement (config 1's 512 x 512 x 64 is)
     const int combo = exact ? 0 : c->refill > 0 ? 3 : c->refill == 0 ? 0 : c->kernelChoice >= 0 ? (c->kernelChoice & 3) : c->tuneState >= 4 ? c->tuneChoice
                     : trial ? kTuneTrial[c->tuneState] : comboDefault;
     const bool refillExtend = (combo & 1) != 0, refillShadow = (combo & 2) != 0;
@@ -628,7 +631,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.ms_total = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (trial) {
         const double rays = (double)(hs.rays_primary + hs.rays_bounce + hs.rays_shadow);
-        if (rays >= 5.0e7 && c->stats.ms_total > 0.0 && c->allocations == allocationsBefore) {
+        if (rays >= 3.0e7 && c->stats.ms_total > 0.0 && c->allocations == allocationsBefore) {
             c->tuneRate[c->tuneState] = rays / c->stats.ms_total;
             if (++c->tuneState == 4) {
                 // trial 0 ran the default of a cache-resident scene, trial 1 that of a large one: another combination

@@ -14,7 +14,7 @@ VEC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vector
 
 # every execution strategy of the core must give the same bits: culled/ordered and reference-order traversal, the
 # dynamic-fetch traversal kernels, one sample per pass on three overlapping streams, a single stream
-VARIANTS = {"culled": {"traversalMode": 0}, "reference_order": {"traversalMode": 1},
+VARIANTS = {"culled": {"traversalMode": 0}, "reference_order": {"traversalMode": 1}, "batch_kernels": {"refill": 0},
             "dynamic_fetch": {"refill": 1, "refillIdle": 24}, "dynamic_fetch_eager": {"refill": 1, "refillIdle": 1},
             "streams3_spp1": {"samplesPerPass": 1, "passStreams": 3}, "one_stream": {"samplesPerPass": 2, "passStreams": 1},
             # shadow rays of a bounce and closest-hit rays of the next in separate launches (the default traces them together),
