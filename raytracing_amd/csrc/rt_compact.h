@@ -4,7 +4,9 @@
 // bit-identical to what the reference recomputes on every test.  Compiled with -ffp-contract=off.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -51,9 +53,9 @@ static inline unsigned parallel_ranges(uint64_t n, uint64_t serialBelow, F f) {
 }
 
 struct CompactScene {
-    std::vector<CNode> nodes;
+    RawBuf<CNode> nodes;
     std::vector<WNode> wnodes;      // two-level view of `nodes` (empty when the tree does not allow it, see derive_wide)
-    std::vector<CTri> tris;         // (released after the upload: nTris keeps the count)
+    RawBuf<CTri> tris;              // (released after the upload: nTris keeps the count)
     RawBuf<CShade> shade;
     RawBuf<CShadeUV> shadeUV;       // filled by fill_shade_uv, only for scenes with a textured material
     uint64_t nTris = 0;
@@ -73,6 +75,168 @@ static inline f3 mul_point(const RefMat4& M, const f3& v, float w) {
     r.z = M.m[0][2] * v.x + M.m[1][2] * v.y + M.m[2][2] * v.z + M.m[3][2] * w;
     return r;
 }
+
+namespace compact_detail {
+
+struct Bounds { float lo[3], hi[3]; };
+static inline Bounds emptyB() { Bounds b; for (int k = 0; k < 3; k++) { b.lo[k] = FLT_MAX; b.hi[k] = -FLT_MAX; } return b; }
+static inline void grow(Bounds& b, const f3& p) {
+    b.lo[0] = std::min(b.lo[0], p.x); b.lo[1] = std::min(b.lo[1], p.y); b.lo[2] = std::min(b.lo[2], p.z);
+    b.hi[0] = std::max(b.hi[0], p.x); b.hi[1] = std::max(b.hi[1], p.y); b.hi[2] = std::max(b.hi[2], p.z);
+}
+static inline void merge(Bounds& b, const Bounds& o) {
+    for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); }
+}
+
+// An internal node at the cut of a big tree: the root of a subtree that is counted and written on its own.
+struct Frontier {
+    uint32_t ref = 0, depth = 0;
+    uint64_t triBefore = 0;              // triangles of the leaves above the cut that are visited before this subtree
+    uint64_t nInt = 0, nTri = 0, nodeBase = 0, triBase = 0;
+    Bounds wb = emptyB(); bool contain = true; uint32_t maxDepth = 0;
+    std::string err;
+};
+
+// The depth-first walk of compact_scene over (a part of) the reference tree, in the shader's visit order.
+// run<true>: validate and count (marks every node it reaches in `seen`).  run<false>: write CNodes from nodeCur and CTris
+// from triCur on, with the world bounds below every node (padded leaf boxes, containment check).
+struct Walk {
+    const RefNode* rnodes = nullptr; uint64_t nNodes = 0, nTris = 0;
+    const f3* wv = nullptr; std::atomic<uint8_t>* seen = nullptr; float padAbs = 0.f;
+    CNode* nodes = nullptr; CTri* tris = nullptr;
+    uint32_t cutDepth = 0xffffffffu; std::vector<Frontier>* frontier = nullptr; size_t nextFrontier = 0;
+    uint64_t nodeCur = 0, triCur = 0, nInt = 0, nTri = 0;
+    bool contain = true; uint32_t maxDepth = 0; Bounds rootWb = emptyB(); std::string err;
+
+    const char* countLeaf(const RefNode& n, uint32_t& cnt) const {
+        cnt = 0;
+        for (int k = 0; k < 4; k++) {
+            const int32_t ti = n.children[k];
+            if (ti == -1) continue;
+            if (ti < 0 || (uint64_t)ti >= nTris) return "leaf references triangle out of range";
+            cnt++;
+        }
+        return nullptr;
+    }
+    // writes the leaf's triangles at cur.., returns the leaf code and the world bounds of the triangles
+    int32_t emitLeaf(const RefNode& n, uint64_t& cur, Bounds& wb) const {
+        const uint32_t first = (uint32_t)cur;
+        uint32_t cnt = 0;
+        wb = emptyB();
+        for (int k = 0; k < 4; k++) {
+            const int32_t ti = n.children[k];
+            if (ti == -1) continue;
+            CTri c;
+            const f3 &a = wv[(uint64_t)ti * 3], &b = wv[(uint64_t)ti * 3 + 1], &cc = wv[(uint64_t)ti * 3 + 2];
+            c.v0[0] = a.x; c.v0[1] = a.y; c.v0[2] = a.z;
+            c.e1[0] = b.x - a.x; c.e1[1] = b.y - a.y; c.e1[2] = b.z - a.z;      // shader.comp:105
+            c.e2[0] = cc.x - a.x; c.e2[1] = cc.y - a.y; c.e2[2] = cc.z - a.z;   // shader.comp:106
+            c.refIndex = ti; c.pad[0] = c.pad[1] = 0;
+            tris[cur++] = c;
+            grow(wb, a); grow(wb, b); grow(wb, cc);
+            cnt++;
+        }
+        // (a leaf without triangles: any non-zero `first`, so that its code differs from -1 = no child at all)
+        return -(int32_t)((cnt ? first : 1u) * 8u + cnt) - 1;
+    }
+    void padBox(const Bounds& wb, float* lo, float* hi) const {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = wb.lo[k] - (padAbs + 1e-5f * std::fabs(wb.lo[k]));
+            hi[k] = wb.hi[k] + (padAbs + 1e-5f * std::fabs(wb.hi[k]));
+        }
+    }
+
+    template <bool DRY>
+    void run(uint32_t rootRef, uint32_t rootDepth) {
+        // Iterative DFS.  Frame state: 0 = fresh, 1 = children.y done, 2 = both done.
+        struct Frame { uint32_t ref; int32_t cidx; int state; Bounds wb; uint32_t depth; };
+        std::vector<Frame> st;
+        auto newInternal = [&](uint32_t ref, uint32_t depth) -> int32_t {
+            Frame f; f.ref = ref; f.cidx = -1; f.state = 0; f.wb = emptyB(); f.depth = depth;
+            if (DRY) nInt++;
+            else {
+                CNode n; std::memset(&n, 0, sizeof n);
+                n.child0 = n.child1 = -1;  // empty leaf code (first 0, count 0)
+                for (int k = 0; k < 3; k++) { n.lo0[k] = n.lo1[k] = FLT_MAX; n.hi0[k] = n.hi1[k] = -FLT_MAX; }
+                nodes[nodeCur] = n;
+                f.cidx = (int32_t)nodeCur++;
+            }
+            st.push_back(f);
+            maxDepth = std::max(maxDepth, depth);
+            return f.cidx;
+        };
+        newInternal(rootRef, rootDepth);
+        while (!st.empty()) {
+            Frame& f = st.back();
+            if (f.state == 2) {
+                if (!DRY) {
+                    // finished: containment check of the reference box against the world bounds below it
+                    const RefNode& rn = rnodes[f.ref];
+                    const float rlo[3] = {rn.minLoc.x, rn.minLoc.y, rn.minLoc.z}, rhi[3] = {rn.maxLoc.x, rn.maxLoc.y, rn.maxLoc.z};
+                    for (int k = 0; k < 3; k++)
+                        if (f.wb.lo[k] <= f.wb.hi[k] && !(rlo[k] <= f.wb.lo[k] && f.wb.hi[k] <= rhi[k])) contain = false;
+                }
+                const Bounds done = f.wb;
+                st.pop_back();
+                if (!st.empty()) merge(st.back().wb, done); else rootWb = done;
+                continue;
+            }
+            const int which = (f.state == 0) ? 1 : 0;   // children.y first (shader.comp:281-284 pushes x then y, pops y)
+            f.state++;
+            const int32_t ci = rnodes[f.ref].children[which];
+            const int32_t cidx = f.cidx;
+            const uint32_t depth = f.depth;
+            if (ci == -1) continue;               // absent child: stays an empty leaf
+            if (DRY) {
+                if (ci < 0 || (uint64_t)ci >= nNodes) { err = "BVH child index out of range"; return; }
+                if (seen[ci].exchange(1, std::memory_order_relaxed)) { err = "BVH node referenced twice (not a tree)"; return; }
+            }
+            const RefNode& cn = rnodes[ci];
+            if (cn.isLeaf == 1) {
+                if (DRY) {
+                    uint32_t cnt;
+                    if (const char* e = countLeaf(cn, cnt)) { err = e; return; }
+                    nTri += cnt;
+                } else {
+                    Bounds wb;
+                    const int32_t code = emitLeaf(cn, triCur, wb);
+                    CNode& pn = nodes[cidx];
+                    float* lo = which ? pn.lo1 : pn.lo0; float* hi = which ? pn.hi1 : pn.hi0;
+                    if (wb.lo[0] <= wb.hi[0]) padBox(wb, lo, hi);
+                    (which ? pn.child1 : pn.child0) = code;
+                    merge(st.back().wb, wb);
+                }
+                maxDepth = std::max(maxDepth, depth + 1);
+            } else if (frontier && depth + 1 >= cutDepth) {
+                // the root of a subtree that is handled on its own
+                if (DRY) { Frontier fr; fr.ref = (uint32_t)ci; fr.depth = depth + 1; fr.triBefore = nTri; frontier->push_back(fr); }
+                else {
+                    const Frontier& fr = (*frontier)[nextFrontier++];
+                    CNode& pn = nodes[cidx];
+                    float* lo = which ? pn.lo1 : pn.lo0; float* hi = which ? pn.hi1 : pn.hi0;
+                    lo[0] = cn.minLoc.x; lo[1] = cn.minLoc.y; lo[2] = cn.minLoc.z;
+                    hi[0] = cn.maxLoc.x; hi[1] = cn.maxLoc.y; hi[2] = cn.maxLoc.z;
+                    (which ? pn.child1 : pn.child0) = (int32_t)fr.nodeBase;
+                    merge(st.back().wb, fr.wb);
+                    if (!fr.contain) contain = false;
+                    maxDepth = std::max(maxDepth, fr.maxDepth);
+                    triCur += fr.nTri;
+                }
+            } else {
+                if (!DRY) {
+                    CNode& pn = nodes[cidx];
+                    float* lo = which ? pn.lo1 : pn.lo0; float* hi = which ? pn.hi1 : pn.hi0;
+                    lo[0] = cn.minLoc.x; lo[1] = cn.minLoc.y; lo[2] = cn.minLoc.z;
+                    hi[0] = cn.maxLoc.x; hi[1] = cn.maxLoc.y; hi[2] = cn.maxLoc.z;
+                }
+                const int32_t nidx = newInternal((uint32_t)ci, depth + 1);   // may reallocate st
+                if (!DRY) (which ? nodes[cidx].child1 : nodes[cidx].child0) = nidx;
+            }
+        }
+    }
+};
+
+}  // namespace compact_detail
 
 // Returns "" on success, else an error message (inconsistent buffers).
 static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts, const RefMat4* mats, uint64_t nMats,
@@ -127,6 +291,8 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
         sceneMaxAbs = maxAbs;
     }
 
+    const bool dbgT = std::getenv("RT_DEBUG") != nullptr;
+    const auto tPhase0 = std::chrono::steady_clock::now();
     // ---- scene scale (for the slack terms of traversalMode 0) ----
     float scale = 0.f;
     for (float m : sceneMaxAbs) scale = std::max(scale, m);
@@ -135,120 +301,87 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
     const float padAbs = 1e-5f * scale;
 
     // ---- walk the reference tree in its own visit order (children.y before children.x) ----
+    // Two passes of one depth-first walk: a dry one that validates the indices, refuses anything that is not a tree and
+    // counts, then one that writes into arrays of exactly that size.  A big tree is cut at kCutDepth: the subtrees below
+    // the cut are counted and written by several threads (each knows where its nodes and its triangles start: triangle
+    // order is the visit order, so a subtree's first index is the count of everything visited before it), the part above
+    // the cut by one.
     out.nodes.clear(); out.tris.clear();
-    out.nodes.reserve(nNodes / 2 + 1); out.tris.reserve(nTris);
-    struct Bounds { float lo[3], hi[3]; };
-    auto emptyB = []() { Bounds b; for (int k = 0; k < 3; k++) { b.lo[k] = FLT_MAX; b.hi[k] = -FLT_MAX; } return b; };
-    auto grow = [](Bounds& b, const f3& p) {
-        b.lo[0] = std::min(b.lo[0], p.x); b.lo[1] = std::min(b.lo[1], p.y); b.lo[2] = std::min(b.lo[2], p.z);
-        b.hi[0] = std::max(b.hi[0], p.x); b.hi[1] = std::max(b.hi[1], p.y); b.hi[2] = std::max(b.hi[2], p.z);
-    };
-    auto merge = [](Bounds& b, const Bounds& o) {
-        for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); }
-    };
-
-    // emit a leaf: appends its triangles, returns the leaf code and its padded world bounds
-    auto emitLeaf = [&](const RefNode& n, Bounds& wb, std::string& err) -> int32_t {
-        uint32_t first = (uint32_t)out.tris.size(), cnt = 0;
-        wb = emptyB();
-        for (int k = 0; k < 4; k++) {
-            int32_t ti = n.children[k];
-            if (ti == -1) continue;
-            if (ti < 0 || (uint64_t)ti >= nTris) { err = "leaf references triangle out of range"; return 0; }
-            CTri c;
-            const f3 &a = wv[(uint64_t)ti * 3], &b = wv[(uint64_t)ti * 3 + 1], &cc = wv[(uint64_t)ti * 3 + 2];
-            c.v0[0] = a.x; c.v0[1] = a.y; c.v0[2] = a.z;
-            c.e1[0] = b.x - a.x; c.e1[1] = b.y - a.y; c.e1[2] = b.z - a.z;      // shader.comp:105
-            c.e2[0] = cc.x - a.x; c.e2[1] = cc.y - a.y; c.e2[2] = cc.z - a.z;   // shader.comp:106
-            c.refIndex = ti; c.pad[0] = c.pad[1] = 0;
-            out.tris.push_back(c);
-            grow(wb, a); grow(wb, b); grow(wb, cc);
-            cnt++;
-        }
-        // (a leaf without triangles: any non-zero `first`, so that its code differs from -1 = no child at all)
-        return -(int32_t)((cnt ? first : 1u) * 8u + cnt) - 1;
-    };
-    auto padBox = [&](const Bounds& wb, float* lo, float* hi) {
-        for (int k = 0; k < 3; k++) {
-            lo[k] = wb.lo[k] - (padAbs + 1e-5f * std::fabs(wb.lo[k]));
-            hi[k] = wb.hi[k] + (padAbs + 1e-5f * std::fabs(wb.hi[k]));
-        }
-    };
-
+    out.maxDepth = 0;
     const RefNode& root = rnodes[0];
     out.rootLo[0] = root.minLoc.x; out.rootLo[1] = root.minLoc.y; out.rootLo[2] = root.minLoc.z;
     out.rootHi[0] = root.maxLoc.x; out.rootHi[1] = root.maxLoc.y; out.rootHi[2] = root.maxLoc.z;
     out.boxesContainTris = true;
-    std::string err;
+
+    std::unique_ptr<std::atomic<uint8_t>[]> seen(new std::atomic<uint8_t>[nNodes]());
+    compact_detail::Walk proto;
+    proto.rnodes = rnodes; proto.nNodes = nNodes; proto.nTris = nTris; proto.wv = wv.data(); proto.seen = seen.get(); proto.padAbs = padAbs;
+
     if (root.isLeaf == 1) {
-        Bounds wb;
-        out.rootChild = emitLeaf(root, wb, err);
-        if (!err.empty()) return err;
         // a lone leaf root keeps the reference's inverted-infinite box, which every ray passes (Q2)
+        compact_detail::Bounds wb;
+        uint32_t cnt = 0;
+        if (const char* e = proto.countLeaf(root, cnt)) return e;
+        out.tris.alloc(cnt);
+        proto.tris = out.tris.data();
+        uint64_t cur = 0;
+        out.rootChild = proto.emitLeaf(root, cur, wb);
         return "";
     }
 
-    // Iterative DFS.  Frame state: 0 = fresh, 1 = children.y done, 2 = both done.
-    struct Frame { uint32_t ref; int32_t cidx; int state; Bounds wb; uint32_t depth; };
-    std::vector<Frame> st;
-    std::vector<uint8_t> seen(nNodes, 0);
-    auto newInternal = [&](uint32_t ref, uint32_t depth) -> int32_t {
-        CNode n; std::memset(&n, 0, sizeof n);
-        n.child0 = n.child1 = -1;  // empty leaf code (first 0, count 0)
-        for (int k = 0; k < 3; k++) { n.lo0[k] = n.lo1[k] = FLT_MAX; n.hi0[k] = n.hi1[k] = -FLT_MAX; }
-        out.nodes.push_back(n);
-        Frame f; f.ref = ref; f.cidx = (int32_t)out.nodes.size() - 1; f.state = 0; f.wb = emptyB(); f.depth = depth;
-        st.push_back(f);
-        out.maxDepth = std::max(out.maxDepth, depth);
-        return f.cidx;
-    };
-    seen[0] = 1;
-    out.rootChild = newInternal(0, 1);
-    while (!st.empty()) {
-        Frame& f = st.back();
-        if (f.state == 2) {
-            // finished: containment check of the reference box against the world bounds below it
-            const RefNode& rn = rnodes[f.ref];
-            const float rlo[3] = {rn.minLoc.x, rn.minLoc.y, rn.minLoc.z}, rhi[3] = {rn.maxLoc.x, rn.maxLoc.y, rn.maxLoc.z};
-            for (int k = 0; k < 3; k++)
-                if (f.wb.lo[k] <= f.wb.hi[k] && !(rlo[k] <= f.wb.lo[k] && f.wb.hi[k] <= rhi[k])) out.boxesContainTris = false;
-            Bounds done = f.wb;
-            st.pop_back();
-            if (!st.empty()) merge(st.back().wb, done);
-            continue;
-        }
-        int which = (f.state == 0) ? 1 : 0;   // children.y first (shader.comp:281-284 pushes x then y, pops y)
-        f.state++;
-        int32_t ci = rnodes[f.ref].children[which];
-        int32_t cidx = f.cidx;
-        uint32_t depth = f.depth;
-        if (ci == -1) continue;               // absent child: stays an empty leaf
-        if (ci < 0 || (uint64_t)ci >= nNodes) return "BVH child index out of range";
-        if (seen[ci]) return "BVH node referenced twice (not a tree)";
-        seen[ci] = 1;
-        const RefNode& cn = rnodes[ci];
-        if (cn.isLeaf == 1) {
-            Bounds wb;
-            int32_t code = emitLeaf(cn, wb, err);
-            if (!err.empty()) return err;
-            CNode& pn = out.nodes[cidx];
-            float* lo = which ? pn.lo1 : pn.lo0; float* hi = which ? pn.hi1 : pn.hi0;
-            if (wb.lo[0] <= wb.hi[0]) padBox(wb, lo, hi);
-            (which ? pn.child1 : pn.child0) = code;
-            merge(st.back().wb, wb);
-            out.maxDepth = std::max(out.maxDepth, depth + 1);
-        } else {
-            {
-                CNode& pn = out.nodes[cidx];
-                float* lo = which ? pn.lo1 : pn.lo0; float* hi = which ? pn.hi1 : pn.hi0;
-                lo[0] = cn.minLoc.x; lo[1] = cn.minLoc.y; lo[2] = cn.minLoc.z;
-                hi[0] = cn.maxLoc.x; hi[1] = cn.maxLoc.y; hi[2] = cn.maxLoc.z;
+    seen[0].store(1, std::memory_order_relaxed);
+    const uint32_t kCutDepth = 11;                                       // at most 1024 subtrees
+    // (RT_COMPACT_PAR / RT_COMPACT_SEQ: force either form, for the test that compares them)
+    const bool parallel = (nNodes >= ((uint64_t)1 << 20) || std::getenv("RT_COMPACT_PAR")) && !std::getenv("RT_COMPACT_SEQ");
+    std::vector<compact_detail::Frontier> frontier;
+    compact_detail::Walk top = proto;
+    top.cutDepth = parallel ? kCutDepth : 0xffffffffu;
+    top.frontier = &frontier;
+    top.run<true>(0, 1);
+    if (!top.err.empty()) return top.err;
+    if (!frontier.empty()) {
+        std::atomic<size_t> next{0};
+        parallel_ranges(64, 1, [&](uint64_t, uint64_t, unsigned) {
+            for (size_t i = next.fetch_add(1); i < frontier.size(); i = next.fetch_add(1)) {
+                compact_detail::Walk w = proto;
+                w.run<true>(frontier[i].ref, frontier[i].depth);
+                frontier[i].nInt = w.nInt; frontier[i].nTri = w.nTri; frontier[i].err = w.err;
             }
-            int32_t nidx = newInternal((uint32_t)ci, depth + 1);   // may reallocate out.nodes / st
-            (which ? out.nodes[cidx].child1 : out.nodes[cidx].child0) = nidx;
+        });
+        uint64_t nodeBase = top.nInt, triSum = 0;
+        for (auto& f : frontier) {
+            if (!f.err.empty()) return f.err;
+            f.nodeBase = nodeBase; nodeBase += f.nInt;
+            f.triBase = f.triBefore + triSum; triSum += f.nTri;
         }
     }
+    uint64_t totalNodes = top.nInt, totalTris = top.nTri;
+    for (const auto& f : frontier) { totalNodes += f.nInt; totalTris += f.nTri; }
+    if (totalNodes >= (1ull << 31)) return "too many BVH nodes";
+    out.nodes.alloc(totalNodes);
+    out.tris.alloc(totalTris);
+    proto.nodes = out.nodes.data(); proto.tris = out.tris.data();
+    if (!frontier.empty()) {
+        std::atomic<size_t> next{0};
+        parallel_ranges(64, 1, [&](uint64_t, uint64_t, unsigned) {
+            for (size_t i = next.fetch_add(1); i < frontier.size(); i = next.fetch_add(1)) {
+                compact_detail::Walk w = proto;
+                w.nodeCur = frontier[i].nodeBase; w.triCur = frontier[i].triBase;
+                w.run<false>(frontier[i].ref, frontier[i].depth);
+                frontier[i].wb = w.rootWb; frontier[i].contain = w.contain; frontier[i].maxDepth = w.maxDepth;
+            }
+        });
+    }
+    {
+        compact_detail::Walk w = proto;
+        w.cutDepth = top.cutDepth; w.frontier = &frontier;
+        w.run<false>(0, 1);
+        out.boxesContainTris = w.contain;
+        out.maxDepth = w.maxDepth;
+        out.rootChild = 0;                                               // the root is the first node the top walk makes
+    }
 
+    const auto tPhase1 = std::chrono::steady_clock::now();
     // Renumber the internal nodes breadth-first: any prefix of the array is then the top of the tree, the part every ray
     // touches, which so stays one contiguous, cache-friendly run.  Triangle order (= visit rank) is untouched.
     {
@@ -263,16 +396,21 @@ static inline std::string compact_scene(const RefVertex* verts, uint64_t nVerts,
             if (nd.child1 >= 0) order.push_back(nd.child1);
         }
         if (order.size() != n) return "internal error: BVH renumbering lost nodes";
-        std::vector<CNode> re(n);
-        for (size_t i = 0; i < n; i++) {
-            CNode nd = out.nodes[(size_t)order[i]];
-            if (nd.child0 >= 0) nd.child0 = newIdx[(size_t)nd.child0];
-            if (nd.child1 >= 0) nd.child1 = newIdx[(size_t)nd.child1];
-            re[i] = nd;
-        }
-        out.nodes.swap(re);
+        RawBuf<CNode> re;
+        re.alloc(n);
+        parallel_ranges(n, 1u << 18, [&](uint64_t lo, uint64_t hi, unsigned) {
+            for (size_t i = lo; i < hi; i++) {
+                CNode nd = out.nodes[(size_t)order[i]];
+                if (nd.child0 >= 0) nd.child0 = newIdx[(size_t)nd.child0];
+                if (nd.child1 >= 0) nd.child1 = newIdx[(size_t)nd.child1];
+                re[i] = nd;
+            }
+        });
+        out.nodes.p.swap(re.p);
         out.rootChild = 0;
     }
+    if (dbgT) std::fprintf(stderr, "[rt] compact_scene: tree walk %.3f s, breadth-first renumbering %.3f s\n",
+                           std::chrono::duration<double>(tPhase1 - tPhase0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tPhase1).count());
     return "";
 }
 

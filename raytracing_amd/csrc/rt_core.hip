@@ -170,10 +170,15 @@ rt_status sync_scene(rt_ctx* c) {
     if (c->sceneDirty) {
         const auto& V = c->slotHost[RT_SLOT_VERTICES]; const auto& M = c->slotHost[RT_SLOT_MESH_MATRICES];
         const auto& N = c->slotHost[RT_SLOT_BVH_NODES]; const auto& T = c->slotHost[RT_SLOT_TRIANGLES];
+        const bool dbgT = std::getenv("RT_DEBUG") != nullptr;
+        auto tNow = [] { return std::chrono::steady_clock::now(); };
+        auto tSec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        const auto tc0 = tNow();
         std::string e = compact_scene((const RefVertex*)V.data(), V.size() / 80, (const RefMat4*)M.data(), M.size() / 64,
                                       c->slotHost[RT_SLOT_MATERIALS].size() / 80, (const RefNode*)N.data(), N.size() / 48,
                                       (const RefTriangle*)T.data(), T.size() / 128, c->cs);
         if (!e.empty()) return fail(c, RT_ERR_SCENE, e);
+        const auto tc1 = tNow();
         rt_status s;
         if ((s = upload(c, c->dNodes, c->cs.nodes.data(), c->cs.nodes.size() * sizeof(CNode)))) return s;
         if ((s = upload(c, c->dTris, c->cs.tris.data(), c->cs.tris.size() * sizeof(CTri)))) return s;
@@ -182,8 +187,9 @@ rt_status sync_scene(rt_ctx* c) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         // the device has them now: the host keeps the node arrays (two-level derivation) and the counts
         c->cs.shade.clear(); c->cs.shadeUV.clear();
-        std::vector<CTri>().swap(c->cs.tris);
+        c->cs.tris.clear();
         c->uvReady = false;
+        if (dbgT) std::fprintf(stderr, "[rt] scene sync: compact layout derived in %.3f s, uploaded in %.3f s\n", tSec(tc0, tc1), tSec(tc1, tNow()));
         c->sceneDirty = false;
         c->tuneState = 0; c->tuneChoice = 0;
         c->wideReady = false; c->cs.wnodes.clear(); c->cs.wideDepth = 0;

@@ -156,6 +156,21 @@ int main(int argc, char** argv) {
         };
         const std::vector<uint8_t> nodes((const uint8_t*)b[3], (const uint8_t*)b[3] + nb[3]), tris((const uint8_t*)b[4], (const uint8_t*)b[4] + nb[4]);
         EXPECT(run(nodes, tris).empty());
+        {   // the walk in one piece and cut into subtrees handled by several threads: the same arrays, byte for byte
+            rt::CompactScene a, b2;
+            setenv("RT_COMPACT_SEQ", "1", 1);
+            EXPECT(rt::compact_scene((const rt::RefVertex*)b[0], nb[0] / 80, (const rt::RefMat4*)b[1], nb[1] / 64, nb[2] / 80,
+                                     (const rt::RefNode*)nodes.data(), nodes.size() / 48, (const rt::RefTriangle*)tris.data(), tris.size() / 128, a).empty());
+            unsetenv("RT_COMPACT_SEQ");
+            setenv("RT_COMPACT_PAR", "1", 1);
+            EXPECT(rt::compact_scene((const rt::RefVertex*)b[0], nb[0] / 80, (const rt::RefMat4*)b[1], nb[1] / 64, nb[2] / 80,
+                                     (const rt::RefNode*)nodes.data(), nodes.size() / 48, (const rt::RefTriangle*)tris.data(), tris.size() / 128, b2).empty());
+            EXPECT(a.nodes.size() == b2.nodes.size() && a.tris.size() == b2.tris.size() && a.nodes.size() > 2048);
+            EXPECT(std::memcmp(a.nodes.data(), b2.nodes.data(), a.nodes.size() * sizeof(rt::CNode)) == 0);
+            EXPECT(std::memcmp(a.tris.data(), b2.tris.data(), a.tris.size() * sizeof(rt::CTri)) == 0);
+            EXPECT(a.maxDepth == b2.maxDepth && a.boxesContainTris == b2.boxesContainTris && a.rootChild == b2.rootChild);
+            // damaged trees are refused by the cut walk too (the cases below run it: RT_COMPACT_PAR stays set)
+        }
         {   // the two-level view of the same tree (knob wideNodes): derived for a tree with nested boxes, refused otherwise
             rt::CompactScene cs;
             EXPECT(rt::compact_scene((const rt::RefVertex*)b[0], nb[0] / 80, (const rt::RefMat4*)b[1], nb[1] / 64, nb[2] / 80,
