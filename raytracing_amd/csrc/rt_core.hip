@@ -1,6 +1,7 @@
 // librt_core.so — C ABI of the MI355X path-tracing core (include/rt_core.h).
 // Host orchestration of the wavefront kernels in rt_kernels.hip.h.  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -52,13 +53,28 @@ struct rt_ctx {
     // The six uploaded buffers as the caller handed them over (rt_upload_buffer copies at once, as glBufferData does).
     // Copied by several threads when large: the first touch of gigabytes of fresh pages by one thread cost 1.5 s at config 4.
     struct HostBuf {
-        std::unique_ptr<uint8_t[]> p; size_t n = 0, cap = 0;
-        const uint8_t* data() const { return p.get(); }
+        uint8_t* p = nullptr; size_t n = 0, cap = 0;
+        HostBuf() = default;
+        HostBuf(const HostBuf&) = delete;
+        HostBuf& operator=(const HostBuf&) = delete;
+        ~HostBuf() { std::free(p); }
+        const uint8_t* data() const { return p; }
         size_t size() const { return n; }
         void assign(const uint8_t* src, size_t bytes) {
-            if (bytes > cap || bytes < cap / 2) { p.reset(bytes ? new uint8_t[bytes] : nullptr); cap = bytes; }
+            if (bytes > cap || bytes < cap / 2) {
+                std::free(p); p = nullptr; cap = 0;
+                if (bytes) {
+                    // large buffers: 2 MB-aligned and advised as huge pages, so that the first touch is a few thousand
+                    // page faults instead of a million
+                    const size_t big = (size_t)64 << 20, align = bytes >= big ? ((size_t)2 << 20) : 64;
+                    p = (uint8_t*)std::aligned_alloc(align, (bytes + align - 1) / align * align);
+                    if (!p) throw std::bad_alloc();
+                    if (bytes >= big) (void)madvise(p, (bytes + align - 1) / align * align, MADV_HUGEPAGE);
+                    cap = bytes;
+                }
+            }
             n = bytes;
-            uint8_t* dst = p.get();
+            uint8_t* dst = p;
             rt::parallel_ranges(bytes, (uint64_t)64 << 20, [&](uint64_t lo, uint64_t hi, unsigned) { if (hi > lo) std::memcpy(dst + lo, src + lo, hi - lo); });
         }
     };
@@ -787,7 +803,8 @@ rt_status rt_upload_buffer(rt_ctx* c, uint32_t slot, const void* data, uint64_t 
     if (slot > 5) return fail(c, RT_ERR_INVALID, "slot must be 0..5");
     if (bytes && !data) return fail(c, RT_ERR_INVALID, "data is NULL");
     if (bytes % kRecordSize[slot]) return fail(c, RT_ERR_INVALID, "size is not a multiple of the slot's record size");
-    c->slotHost[slot].assign((const uint8_t*)data, (size_t)bytes);
+    try { c->slotHost[slot].assign((const uint8_t*)data, (size_t)bytes); }
+    catch (const std::bad_alloc&) { return fail(c, RT_ERR_HIP, "out of host memory for the copy of slot " + std::to_string(slot)); }
     c->slotSet[slot] = true;
     if (slot == RT_SLOT_LIGHTS) c->lightsDirty = true;
     else if (slot == RT_SLOT_MATERIALS) { c->materialsDirty = true; c->sceneDirty = true; }
