@@ -2,6 +2,7 @@
 #include "rt_host.hpp"
 
 #include <sys/stat.h>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +11,7 @@
 
 #include "../../../include/rt_host.h"
 #include "bvh_build.h"
+#include "../rt_compact.h"      // RawBuf, parallel_ranges
 
 namespace rt_host {
 
@@ -275,7 +277,14 @@ std::vector<mat4> Model::getMatricesMeshes() {
 // model.cpp:532-613
 std::vector<GPUBoundingBox> Model::BVH() {
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<Triangle> triangles;
+    // (one exactly sized, not zero-filled array, written by several threads for big meshes: 2.5 GB at 20 M triangles)
+    rt::RawBuf<Triangle> triangles;
+    {
+        size_t total = 0;
+        for (Model* model : instances) for (Mesh& mesh : model->meshes) total += mesh.indices.size() / 3;
+        triangles.alloc(total);
+    }
+    size_t triCursor = 0;
     std::vector<Vertex> verticesList;
     std::vector<mat4> meshMatrices;
     std::vector<MaterialData> materialList;
@@ -288,26 +297,32 @@ std::vector<GPUBoundingBox> Model::BVH() {
         for (size_t meshIdx = 0; meshIdx < model->meshes.size(); meshIdx++) {
             Mesh& mesh = model->meshes[meshIdx];
             verticesList.insert(verticesList.end(), mesh.vertices.begin(), mesh.vertices.end());
-            triangles.reserve(triangles.size() + mesh.indices.size() / 3);
             // material looked up by traversal position, not glTF mesh id (Q16, model.cpp:574)
-            uint32_t materialIdx = (uint32_t)model->JSON["meshes"][meshIdx]["primitives"][0].value("material", 0) + materialOffset;
-            for (size_t i = 0; i + 2 < mesh.indices.size(); i += 3) {
-                uint32_t ia = mesh.indices[i], ib = mesh.indices[i + 1], ic = mesh.indices[i + 2];
-                if (ia >= mesh.vertices.size() || ib >= mesh.vertices.size() || ic >= mesh.vertices.size())
-                    throw std::runtime_error("mesh index out of range");
-                Triangle t; std::memset(&t, 0, sizeof t);
-                t.p1 = mesh.vertices[ia].position; t.p2 = mesh.vertices[ib].position; t.p3 = mesh.vertices[ic].position;
-                // indices pass through float (Q13, model.cpp:575): vec3(i) + vec3(offset) -> uvec3
-                t.indices[0] = (uint32_t)((float)ia + (float)indiceOffset);
-                t.indices[1] = (uint32_t)((float)ib + (float)indiceOffset);
-                t.indices[2] = (uint32_t)((float)ic + (float)indiceOffset);
-                vec3 p1(t.p1.x, t.p1.y, t.p1.z), p2(t.p2.x, t.p2.y, t.p2.z), p3(t.p3.x, t.p3.y, t.p3.z);
-                vec3 c = (p1 + p2 + p3) / 3.f;                                  // model.h:54
-                vec3 mn = vmin(vmin(p1, p2), p3), mx = vmax(vmax(p1, p2), p3);  // model.h:55-56
-                t.centroidLoc = {c.x, c.y, c.z}; t.minBounds = {mn.x, mn.y, mn.z}; t.maxBounds = {mx.x, mx.y, mx.z};
-                t.meshIndex = meshOffset + (uint32_t)meshIdx; t.materialIndex = materialIdx;
-                triangles.push_back(t);
-            }
+            const uint32_t materialIdx = (uint32_t)model->JSON["meshes"][meshIdx]["primitives"][0].value("material", 0) + materialOffset;
+            const size_t nT = mesh.indices.size() / 3;
+            const uint32_t meshIndex = meshOffset + (uint32_t)meshIdx;
+            Triangle* dst = triangles.data() + triCursor;
+            std::atomic<bool> bad{false};
+            rt::parallel_ranges(nT, 1u << 18, [&](uint64_t lo, uint64_t hi, unsigned) {
+                for (size_t k = lo; k < hi; k++) {
+                    const uint32_t ia = mesh.indices[3 * k], ib = mesh.indices[3 * k + 1], ic = mesh.indices[3 * k + 2];
+                    if (ia >= mesh.vertices.size() || ib >= mesh.vertices.size() || ic >= mesh.vertices.size()) { bad = true; return; }
+                    Triangle t; std::memset(&t, 0, sizeof t);
+                    t.p1 = mesh.vertices[ia].position; t.p2 = mesh.vertices[ib].position; t.p3 = mesh.vertices[ic].position;
+                    // indices pass through float (Q13, model.cpp:575): vec3(i) + vec3(offset) -> uvec3
+                    t.indices[0] = (uint32_t)((float)ia + (float)indiceOffset);
+                    t.indices[1] = (uint32_t)((float)ib + (float)indiceOffset);
+                    t.indices[2] = (uint32_t)((float)ic + (float)indiceOffset);
+                    vec3 p1(t.p1.x, t.p1.y, t.p1.z), p2(t.p2.x, t.p2.y, t.p2.z), p3(t.p3.x, t.p3.y, t.p3.z);
+                    vec3 c = (p1 + p2 + p3) / 3.f;                                  // model.h:54
+                    vec3 mn = vmin(vmin(p1, p2), p3), mx = vmax(vmax(p1, p2), p3);  // model.h:55-56
+                    t.centroidLoc = {c.x, c.y, c.z}; t.minBounds = {mn.x, mn.y, mn.z}; t.maxBounds = {mx.x, mx.y, mx.z};
+                    t.meshIndex = meshIndex; t.materialIndex = materialIdx;
+                    dst[k] = t;
+                }
+            });
+            if (bad) throw std::runtime_error("mesh index out of range");
+            triCursor += nT;
             indiceOffset += (uint32_t)mesh.vertices.size();
         }
         meshOffset += (uint32_t)model->meshes.size();
