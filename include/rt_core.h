@@ -79,7 +79,7 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * sum is still replayed in sample order, so results do not depend on it), refill (-1 automatic / 0 / 1: persistent
  * traversal waves that hand finished lanes new rays; automatic = the first four sizeable frames after a scene upload
  * are rendered with the four combinations (refill or not, for closest-hit and for shadow rays) and the fastest is kept;
- * until then BVHs far larger than the L2s use them and others do not), kernelChoice (-1 / 0..3: that combination whatever
+ * until then closest-hit rays of bounces >= 1 use them, and shadow rays do where the BVH is far larger than the L2s), kernelChoice (-1 / 0..3: that combination whatever
  * was measured, reported back in rt_stats.kernel_choice; a multi-GPU job gives every rank rank 0's), fusePairs (1 / 0: the
  * shadow rays of a bounce and the closest-hit rays of the next are traced by one launch), wideNodes (-1 / 0 / 1: the refill
  * kernels walk two-level nodes derived from the same tree, by default for BVHs far larger than the L2s; same images), refillIdle, refillNodeMin,

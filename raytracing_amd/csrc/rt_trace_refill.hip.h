@@ -7,7 +7,8 @@
 // hands those lanes new rays and goes on, which keeps more independent misses in flight per wave.  Work distribution
 // uses no atomics (one contended counter word costs ~30 ns per grab on MI355X): wave w owns the 64-ray groups
 // w, w + nWaves, w + 2 nWaves ... of the queue, so the resident waves work on one compact window of the queue and of the
-// path-state arrays.  On cache-resident scenes (C1-C3, C5) the batch kernels are faster and stay the default.
+// path-state arrays.  With the leaf parking below the closest-hit kernel is the faster one on the cache-resident scenes too
+// (bounce rays; camera rays stay on the batch kernel), and which pair of kernels a scene gets is measured (rt_core.hip).
 //
 // Per-ray arithmetic: that of closest_hit<false,..,true> / occluded_fast<..,true> (shader.comp:104-125, 171-184,
 // 243-290) — same expressions, same order.  Rays that could produce a NaN in a slab test take the select-form routines
