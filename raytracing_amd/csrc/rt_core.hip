@@ -87,7 +87,7 @@ struct rt_ctx {
     float camPos[3] = {0, 0, 0}, camForward[3] = {0, 0, -1}, camRight[3] = {1, 0, 0}, camUp[3] = {0, 1, 0};
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
-    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64;
+    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64, sampleGroup = 4;
 
     // device scene
     DevBuf dNodes, dWNodes, dTris, dShade, dShadeUV, dMaterials, dCMat, dVertices, dLights, dTexDescs;
@@ -361,7 +361,7 @@ PathBuffers make_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
     P.hit = (float2*)ps.hit.p; P.shadowRec = (float4*)ps.shadowRec.p; P.shadeLoc = (float4*)ps.shadeLoc.p;
     P.contrib = (float4*)ps.contrib.p; P.depth = (uint32_t*)ps.depth.p; P.accum = (float4*)c->accum.p;
     P.counters = (uint32_t*)ps.counters.p;
-    P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots;
+    P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots; P.grpShift = 0;
     P.overflow = (uint2*)ps.overflow.p; P.overflowStride = stack_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
 }
@@ -538,6 +538,11 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         uint32_t* scount = P.counters + (maxB + 1);
         PathBuffers Pp = P;
         Pp.nslots = inPass * sps;                  // a short last pass uses its own (smaller) log strides
+        {   // samples per group of 64 slots (slot_split): the largest power of two <= 2^sampleGroup that divides the pass
+            uint32_t sh = (uint32_t)std::min(std::max(c->sampleGroup, 0), 6);
+            while (sh > 0 && (inPass & ((1u << sh) - 1u)) != 0u) sh--;
+            Pp.grpShift = sh;
+        }
         const uint32_t passBlocks = (Pp.nslots + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t tb = std::min(traceBlocks, passBlocks);
         HIPCHK(c, hipMemsetAsync(P.counters, 0, (size_t)(2 * (maxB + 1)) * 4, st));
@@ -822,6 +827,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "timeKernels")) c->timeKernels = v;
     else if (name_is(name, "countVisits")) c->countVisits = v;
     else if (name_is(name, "samplesPerPass")) c->samplesPerPass = v;
+    else if (name_is(name, "sampleGroup")) c->sampleGroup = v;
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
@@ -1073,7 +1079,7 @@ rt_status rt_trace_rays_noalloc(rt_ctx* c, const float* origins, const float* di
     PathBuffers P;
     std::memset(&P, 0, sizeof P);
     P.ray[0] = dRay; P.hit = dHit; P.counters = dCount;
-    P.nslots = nslots; P.slotsPerSample = nslots; P.lightSlots = 1;
+    P.nslots = nslots; P.slotsPerSample = nslots; P.lightSlots = 1; P.grpShift = 0;
     P.overflow = dOv; P.overflowStride = ovStride; P.overflowDepth = ovDepth;
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;

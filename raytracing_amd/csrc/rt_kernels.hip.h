@@ -32,7 +32,7 @@ struct PathBuffers {
                          // hitLoc = o + d * t is recomputed by k_shade
     float4* shadowRec;   // shadow-queue entry j: (origin.xyz, slot bits)
     float4* shadeLoc;    // [slot] hitLoc of the bounce being shaded, written only when a point light needs it (k_shadow)
-    // Indexed by slot (= sampleInPass * slotsPerSample + tileSlot), because k_resolve replays them per pixel:
+    // Indexed by slot (one per sample of the pass and pixel: slot_split), because k_resolve replays them per pixel:
     float4* contrib;     // contribution log [maxBounces][lightSlots][nslots]: rgb, w = 0 none / 1 awaiting shadow ray / 2 add
     uint32_t* depth;     // [nslots] bounces shaded by the slot's path (log entries [0, depth) are valid)
     float4* accum;       // [slotsPerSample] running pixel colour (the shader's `color`), survives passes, shared by all sets
@@ -41,6 +41,7 @@ struct PathBuffers {
     uint32_t overflowStride, overflowDepth;
     uint32_t nslots;     // slots in flight = samples per pass x slotsPerSample
     uint32_t slotsPerSample, lightSlots;   // lightSlots = max(1, numLights)
+    uint32_t grpShift;   // a group of 64 slots holds 2^grpShift samples of 64 >> grpShift pixels (slot_split)
 };
 
 __device__ __forceinline__ void unpack_ray(float4 a, float4 b, v3& o, v3& d, uint32_t& flags, uint32_t& slot) {
@@ -420,6 +421,27 @@ __device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, in
     return occ;
 }
 
+// Slot numbering of a pass.  A slot is one (sample of the pass, pixel) pair; bounce 0 has no queue (entry i of its launches
+// is slot i), and later queues keep that order, so the numbering decides which rays share a wave.  A group of 64
+// consecutive slots holds 2^grpShift consecutive samples of 64 >> grpShift neighbouring pixels (pixel slots in tile order,
+// slot_to_pixel): with grpShift = 0 a wave traces one sample of an 8 x 8 pixel tile, with grpShift = 6 sixty-four samples of
+// one pixel — rays that start together and, for the camera and the sun's shadow rays, run side by side through the tree.
+// Groups are ordered sample block first, pixel group second.  (The pass's sample count is a multiple of 2^grpShift and
+// slotsPerSample a multiple of 64: rt_core.hip.)
+__device__ __forceinline__ void slot_split(const PathBuffers& P, uint32_t slot, uint32_t* sample, uint32_t* pixelSlot) {
+    const uint32_t sh = P.grpShift, psh = 6u - sh;
+    const uint32_t l = slot & 63u, G = slot >> 6;
+    const uint32_t nPG = P.slotsPerSample >> psh;            // pixel groups per sample block
+    const uint32_t sb = G / nPG, pg = G - sb * nPG;
+    *sample = (sb << sh) + (l >> psh);
+    *pixelSlot = (pg << psh) + (l & ((1u << psh) - 1u));
+}
+__device__ __forceinline__ uint32_t slot_of(const PathBuffers& P, uint32_t sample, uint32_t pixelSlot) {
+    const uint32_t sh = P.grpShift, psh = 6u - sh;
+    const uint32_t nPG = P.slotsPerSample >> psh;
+    return ((((sample >> sh) * nPG + (pixelSlot >> psh)) << 6) | ((sample & ((1u << sh) - 1u)) << psh) | (pixelSlot & ((1u << psh) - 1u)));
+}
+
 // ---------------------------------------------------------------------------------------------
 // shader.comp:309-324: the camera ray of slot `slot` (sample rBase + slot / slotsPerSample of its pixel).  Bounce 0
 // needs neither a queue nor stored rays: every slot carries a path and k_extend / k_shade regenerate the ray from
@@ -429,8 +451,10 @@ __device__ __forceinline__ bool occluded_fast(const SceneView& S, v3 o, v3 d, in
 __device__ __forceinline__ bool primary_ray(const FrameParams& F, const PathBuffers& P, int rBase, uint32_t slot,
                                             int* pxOut, int* pyOut, int* rOut, v3* dirOut) {
     int px, py;
-    int r = rBase + (int)(slot / P.slotsPerSample);
-    slot_to_pixel(F, slot % P.slotsPerSample, &px, &py);
+    uint32_t sm, ps;
+    slot_split(P, slot, &sm, &ps);
+    int r = rBase + (int)sm;
+    slot_to_pixel(F, ps, &px, &py);
     *pxOut = px; *pyOut = py; *rOut = r;
     int N = F.gridN;
     int gx = r % N, gy = r / N;
@@ -840,8 +864,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(SceneView S,
                 unpack_ray(raysIn[2u * i], raysIn[2u * i + 1u], rayLoc, rayDir, fl, slot);
                 strength = mk(s4.x, s4.y, s4.z);
                 refracting = (fl & RT_FLAG_REFRACTING) != 0u;
-                r = rBase + (int)(slot / P.slotsPerSample);
-                slot_to_pixel(F, slot % P.slotsPerSample, &px, &py);
+                uint32_t sm, ps;
+                slot_split(P, slot, &sm, &ps);
+                r = rBase + (int)sm;
+                slot_to_pixel(F, ps, &px, &py);
             }
             int ref = __float_as_int(h2.y);
             const v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122); only used for hits
@@ -1043,7 +1069,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathBuffers P, int samples
     if (ps >= P.slotsPerSample) return;
     float4 acc = P.accum[ps];
     for (int sm = 0; sm < samplesInPass; sm++) {
-        uint32_t slot = (uint32_t)sm * P.slotsPerSample + ps;
+        uint32_t slot = slot_of(P, (uint32_t)sm, ps);
         uint32_t d = P.depth[slot];
         for (uint32_t b = 0; b < d; b++) {
             const float4* logp = P.contrib + (size_t)b * P.lightSlots * P.nslots + slot;

@@ -24,7 +24,10 @@ VARIANTS = {"culled": {"traversalMode": 0}, "reference_order": {"traversalMode":
             # two-level nodes in the refill kernels: joint launches with either or both kinds, separate launches, eager refills
             "wide_refill_refill": {"kernelChoice": 3, "wideNodes": 1}, "wide_refill_batch": {"kernelChoice": 1, "wideNodes": 1},
             "wide_batch_refill": {"kernelChoice": 2, "wideNodes": 1},
-            "wide_separate": {"refill": 1, "refillIdle": 1, "fusePairs": 0, "wideNodes": 1}}
+            "wide_separate": {"refill": 1, "refillIdle": 1, "fusePairs": 0, "wideNodes": 1},
+            # bounce 0 in groups of 64 / 16 / 4 samples of 1 / 4 / 16 pixels per wave instead of one sample of 64 pixels
+            "sample_groups_64": {"sampleGroup": 6}, "sample_groups_16_refill": {"sampleGroup": 4, "kernelChoice": 3},
+            "sample_groups_4_spp3": {"sampleGroup": 2, "samplesPerPass": 3}}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
