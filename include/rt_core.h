@@ -75,7 +75,8 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * reference's result: boxes that do not contain their triangles, trees 63 or more levels deep), timeKernels (1 = HIP-event timing per kernel class into rt_stats), countVisits (1 = run the
  * instrumented traversal kernels that count node visits / triangle tests), samplesPerPass (samples of a pixel
  * traced concurrently; results do not depend on it), sampleGroup (0..6, default 4: a wave of the camera-ray launch holds
- * 2^sampleGroup samples of 64 >> sampleGroup neighbouring pixels; results do not depend on it), blocksPerCU (persistent grid size), passStreams (1..8, default 4: consecutive
+ * 2^sampleGroup samples of 64 >> sampleGroup neighbouring pixels; results do not depend on it), pathMemPercent (default 75: share of device memory the path state may take; caps the
+ * samples per pass), blocksPerCU (persistent grid size), passStreams (1..8, default 4: consecutive
  * passes of samplesPerPass samples run on that many HIP streams with their own path buffers and overlap; the per-pixel
  * sum is still replayed in sample order, so results do not depend on it), refill (-1 automatic / 0 / 1: persistent
  * traversal waves that hand finished lanes new rays; automatic = the first four sizeable frames after a scene upload

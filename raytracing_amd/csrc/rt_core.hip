@@ -87,7 +87,7 @@ struct rt_ctx {
     float camPos[3] = {0, 0, 0}, camForward[3] = {0, 0, -1}, camRight[3] = {1, 0, 0}, camUp[3] = {0, 1, 0};
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
-    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64, sampleGroup = 4;
+    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64, sampleGroup = 4, pathMemPercent = 75;
 
     // device scene
     DevBuf dNodes, dWNodes, dTris, dShade, dShadeUV, dMaterials, dCMat, dVertices, dLights, dTexDescs;
@@ -418,7 +418,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     {
         const uint64_t bytesPerSlot = 2 * 32 + 2 * 16 + 8 + 16 + 16 + 4 + 16ull * (uint64_t)std::max(1, F.numLights) * std::max<uint32_t>(1, maxB);
         const uint64_t wantSets = (uint64_t)std::min<int>(std::max(1, (int)c->passStreams), rt_ctx::kMaxSets);
-        uint64_t slotBudget = std::min<uint64_t>(1ull << 30, (c->deviceBytes / 2) / (wantSets * bytesPerSlot));
+        uint64_t slotBudget = std::min<uint64_t>(1ull << 30, (c->deviceBytes / 100 * (uint64_t)std::min(std::max(c->pathMemPercent, 1), 90)) / (wantSets * bytesPerSlot));
         if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
     }
     if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
@@ -427,6 +427,22 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     if (c->autoPass != 0 && c->passStreams > 1) {
         const uint32_t want = (r1 - r0 + (uint32_t)c->passStreams - 1) / (uint32_t)c->passStreams;
         if (want < S_) S_ = std::max<uint32_t>(std::min<uint32_t>(16u, S_), want);
+    }
+    // Whole sample groups (slot_split: 2^sampleGroup samples of a pixel share a wave), and as many passes as fill the
+    // streams evenly: 6 passes on 4 streams leave two streams idle for the last third of the frame.
+    {
+        const uint32_t n = r1 - r0;
+        uint32_t q = 1u << (uint32_t)std::min(std::max(c->sampleGroup, 0), 6);
+        while (q > 1u && q > S_) q >>= 1;
+        S_ -= S_ % q;
+        const uint32_t streams = (uint32_t)std::min<int>(std::max(1, (int)c->passStreams), rt_ctx::kMaxSets);
+        uint32_t nPasses = (n + S_ - 1) / S_;
+        if (c->autoPass != 0 && nPasses > streams && nPasses % streams != 0u) {
+            nPasses += streams - nPasses % streams;
+            uint32_t even = (n + nPasses - 1) / nPasses;
+            even = (even + q - 1) / q * q;
+            if (even >= 1u && even <= S_) S_ = even;
+        }
     }
     const uint32_t lightSlots = (uint32_t)std::max(1, F.numLights);
 
@@ -828,6 +844,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "countVisits")) c->countVisits = v;
     else if (name_is(name, "samplesPerPass")) c->samplesPerPass = v;
     else if (name_is(name, "sampleGroup")) c->sampleGroup = v;
+    else if (name_is(name, "pathMemPercent")) c->pathMemPercent = v;
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;

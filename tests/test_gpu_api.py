@@ -61,6 +61,37 @@ def test_samples_per_pass_does_not_change_the_image(oracle_lib, scene7):
     cs.Delete()
 
 
+def test_sample_groups_and_pass_shapes_do_not_change_the_image(oracle_lib, scene7):
+    """Slot numbering (sampleGroup: 1 .. 64 samples of a pixel per wave), ragged and evened-out passes (13 samples over 3
+    streams, 4 + 4 + 4 + 1 or as given) and a path-state budget so small that it sets the pass size: all four images, the
+    primary ids and the ray counts are those of the oracle-checked default."""
+    from raytracing_amd import ComputeShader
+    W, H, spp, b = 72, 40, 13, 8          # 72 x 40: nine 8 x 8 tile columns, the last pixel group of a row of tiles is ragged for no setting
+    cs = ComputeShader()
+    setup_core(cs, scene7, W, H, spp, b)
+    first = _render(cs)
+    want = oracle_lib.render(scene7, oracle_lib.make_params(scene7, W, H, spp, b, math_mode=1))
+    for k, name in enumerate(("color", "albedo", "normal", "depth")):
+        assert same_floats(first[k], want[name]).all(), name
+    tri0, hit0 = cs.primary_hits()
+    rays0 = [cs.stats()[k] for k in ("rays_primary", "rays_bounce", "rays_shadow", "rays_shadow_skipped")]
+    defaults = {"sampleGroup": 4, "samplesPerPass": 64, "passStreams": 0, "autoPass": 1, "pathMemPercent": 75, "kernelChoice": -1}
+    for knobs in ({"sampleGroup": 0}, {"sampleGroup": 6}, {"sampleGroup": 3, "samplesPerPass": 12}, {"sampleGroup": 2, "samplesPerPass": 4, "passStreams": 3},
+                  {"sampleGroup": 6, "samplesPerPass": 5, "autoPass": 0}, {"sampleGroup": 1, "samplesPerPass": 3, "passStreams": 2, "kernelChoice": 3},
+                  {"pathMemPercent": 1, "sampleGroup": 2}):
+        for k, v in knobs.items():
+            cs.setInt(k, v)
+        imgs = _render(cs)
+        for k in range(4):
+            assert same_floats(imgs[k], first[k]).all(), (knobs, k)
+        tri, hit = cs.primary_hits()
+        assert np.array_equal(tri, tri0) and same_floats(hit, hit0).all(), knobs
+        assert [cs.stats()[k] for k in ("rays_primary", "rays_bounce", "rays_shadow", "rays_shadow_skipped")] == rays0, knobs
+        for k in knobs:
+            cs.setInt(k, defaults[k])
+    cs.Delete()
+
+
 def test_region_is_bit_identical_and_sample_ranges_sum(oracle_lib, scene4):
     from raytracing_amd import ComputeShader
     W, H, spp, b = 64, 48, 4, 6
