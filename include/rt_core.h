@@ -74,8 +74,11 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * exhaustive with the shader's 64-entry stack; 0 becomes 1 by itself for a scene on which culling would not give the
  * reference's result: boxes that do not contain their triangles, trees 63 or more levels deep), timeKernels (1 = HIP-event timing per kernel class into rt_stats), countVisits (1 = run the
  * instrumented traversal kernels that count node visits / triangle tests), samplesPerPass (samples of a pixel
- * traced concurrently; results do not depend on it), sampleGroup (0..6, default 4: a wave of the camera-ray launch holds
- * 2^sampleGroup samples of 64 >> sampleGroup neighbouring pixels; results do not depend on it), pathMemPercent (default 75: share of device memory the path state may take; caps the
+ * traced concurrently; results do not depend on it), sampleGroup (0..6; default -1 = 4, or 6 where the BVH is far larger than the L2s: a wave of the camera-ray launch holds
+ * 2^sampleGroup samples of 64 >> sampleGroup neighbouring pixels; results do not depend on it), logDenseBounces (0 automatic: 4 when maxBounces > 8, else all) and lateLogPercent (default 25): the
+ * contribution log keeps an entry per slot for that many bounces and, for the later ones, per queue position, as many as that
+ * share of the slots (a frame that needs more is rendered again with a dense log; results do not depend on either),
+ * pathMemPercent (default 50: share of device memory the path state may take; caps the
  * samples per pass), blocksPerCU (persistent grid size), passStreams (1..8, default 4: consecutive
  * passes of samplesPerPass samples run on that many HIP streams with their own path buffers and overlap; the per-pixel
  * sum is still replayed in sample order, so results do not depend on it), refill (-1 automatic / 0 / 1: persistent
@@ -163,6 +166,9 @@ typedef struct rt_stats {
                                   (k_trace_pair, knob fusePairs); they are counted and timed under launches_extend / ms_extend */
     int32_t  wide_nodes;       /* 1: the refill kernels of this call walked two-level nodes (knob wideNodes and a tree that qualifies) */
     int32_t  wide_depth;       /* two-level steps on the longest root-to-leaf path (0: not derived) */
+    int32_t  log_dense_bounces;  /* bounces whose contribution log holds an entry per slot; later bounces log by queue position
+                                    (knobs logDenseBounces, lateLogPercent; == maxBounces: the whole log is dense) */
+    int32_t  log_fallbacks;      /* frames of this context rendered twice because the compact part of the log overflowed */
 } rt_stats;
 rt_status rt_get_stats(rt_ctx* ctx, rt_stats* out);
 

@@ -27,7 +27,8 @@ class RtStats(C.Structure):
                 ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64),
                 ("ms_extend_primary", C.c_double), ("launches_extend_primary", C.c_uint64),
                 ("kernel_choice", C.c_int32), ("kernel_choice_settled", C.c_int32),
-                ("launches_pair", C.c_uint64), ("wide_nodes", C.c_int32), ("wide_depth", C.c_int32)]
+                ("launches_pair", C.c_uint64), ("wide_nodes", C.c_int32), ("wide_depth", C.c_int32),
+                ("log_dense_bounces", C.c_int32), ("log_fallbacks", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

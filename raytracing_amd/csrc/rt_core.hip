@@ -87,7 +87,9 @@ struct rt_ctx {
     float camPos[3] = {0, 0, 0}, camForward[3] = {0, 0, -1}, camRight[3] = {1, 0, 0}, camUp[3] = {0, 1, 0};
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
-    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64, sampleGroup = 4, pathMemPercent = 75;
+    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64, sampleGroup = -1, pathMemPercent = 50, logDenseBounces = 0, lateLogPercent = 25;
+    uint32_t lateLogFallbacks = 0;
+    bool lateLogOff = false;      // a frame overflowed the compact part of the log: this context keeps a dense log from then on
 
     // device scene
     DevBuf dNodes, dWNodes, dTris, dShade, dShadeUV, dMaterials, dCMat, dVertices, dLights, dTexDescs;
@@ -105,7 +107,7 @@ struct rt_ctx {
     // path state
     // Up to kMaxSets sets of per-pass path buffers: consecutive passes run on `passStreams` streams, so that the small, tail-dominated
     // launches of one pass's late bounces overlap the large launches of the next pass (only k_resolve is ordered).
-    struct PathSet { DevBuf ray[2], rayS[2], hit, shadowRec, shadeLoc, contrib, depth, counters, overflow; };
+    struct PathSet { DevBuf ray[2], rayS[2], hit, shadowRec, shadeLoc, contrib, depth, counters, overflow, late, lateNext, lateHead; };
     static constexpr int kMaxSets = 8;
     PathSet set[kMaxSets];
     DevBuf accum, dStats;
@@ -330,8 +332,24 @@ uint32_t overflow_depth(rt_ctx* c) {
 }
 
 void release_set(rt_ctx::PathSet& ps) {
-    DevBuf* pb[] = {&ps.ray[0], &ps.ray[1], &ps.rayS[0], &ps.rayS[1], &ps.hit, &ps.shadowRec, &ps.shadeLoc, &ps.contrib, &ps.depth, &ps.counters, &ps.overflow};
+    DevBuf* pb[] = {&ps.ray[0], &ps.ray[1], &ps.rayS[0], &ps.rayS[1], &ps.hit, &ps.shadowRec, &ps.shadeLoc, &ps.contrib, &ps.depth, &ps.counters, &ps.overflow, &ps.late, &ps.lateNext, &ps.lateHead};
     for (DevBuf* b : pb) b->release();
+}
+
+// The contribution log of a pass: planes [0, dense) hold an entry per slot; the bounces from `dense` on, which few paths
+// reach when the bounce limit is high, hold `lateCap` entries each, addressed by queue position (PathBuffers, k_shade).
+struct LogShape { uint32_t dense, lateBounces, lateCap; };
+LogShape log_shape(rt_ctx* c, uint32_t nslots, uint32_t maxBounces) {
+    LogShape g;
+    const uint32_t maxB = std::max<uint32_t>(1, maxBounces);
+    int dense = c->logDenseBounces;
+    if (dense <= 0) dense = maxB > 8 ? 4 : (int)maxB;      // automatic: two parts only where the log dominates the path state
+    if (c->lateLogOff) dense = (int)maxB;
+    g.dense = std::min<uint32_t>((uint32_t)dense, maxB);
+    g.lateBounces = maxB - g.dense;
+    const uint64_t cap = ((uint64_t)nslots * (uint64_t)std::min(std::max(c->lateLogPercent, 1), 100) / 100 + 63) / 64 * 64;
+    g.lateCap = g.lateBounces ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), (uint64_t)nslots + 63) : 0u;
+    return g;
 }
 
 rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
@@ -346,7 +364,13 @@ rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
     if ((s = ensure(c, ps.shadowRec, n * 16))) return s;
     if ((s = ensure(c, ps.shadeLoc, n * 16))) return s;
     if ((s = ensure(c, ps.hit, n * 8))) return s;
-    if ((s = ensure(c, ps.contrib, n * 16 * lightSlots * std::max<uint32_t>(1, maxBounces)))) return s;
+    const LogShape g = log_shape(c, nslots, maxBounces);
+    if ((s = ensure(c, ps.contrib, n * 16 * lightSlots * g.dense))) return s;
+    if (g.lateBounces) {
+        if ((s = ensure(c, ps.late, (size_t)g.lateBounces * lightSlots * g.lateCap * 16))) return s;
+        if ((s = ensure(c, ps.lateNext, (size_t)g.lateBounces * g.lateCap * 4))) return s;
+        if ((s = ensure(c, ps.lateHead, n * 4))) return s;
+    }
     if ((s = ensure(c, ps.depth, n * 4))) return s;
     if ((s = ensure(c, c->accum, (size_t)slotsPerSample * 16))) return s;
     if ((s = ensure(c, ps.counters, (size_t)(2 * (maxBounces + 1)) * 4))) return s;
@@ -354,7 +378,7 @@ rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
     return RT_OK;
 }
 
-PathBuffers make_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots) {
+PathBuffers make_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
     PathBuffers P;
     rt_ctx::PathSet& ps = c->set[which];
     for (int k = 0; k < 2; k++) { P.ray[k] = (float4*)ps.ray[k].p; P.rayS[k] = (float4*)ps.rayS[k].p; }
@@ -362,6 +386,9 @@ PathBuffers make_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
     P.contrib = (float4*)ps.contrib.p; P.depth = (uint32_t*)ps.depth.p; P.accum = (float4*)c->accum.p;
     P.counters = (uint32_t*)ps.counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots; P.grpShift = 0;
+    const LogShape g = log_shape(c, nslots, maxBounces);
+    P.late = (float4*)ps.late.p; P.lateNext = (uint32_t*)ps.lateNext.p; P.lateHead = (uint32_t*)ps.lateHead.p;
+    P.denseBounces = g.lateBounces ? g.dense : 0xffffffffu; P.lateCap = g.lateCap;
     P.overflow = (uint2*)ps.overflow.p; P.overflowStride = stack_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
 }
@@ -416,7 +443,10 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     // Slot budget: all `passStreams` buffer sets together may take half of the device's memory (the scene, the
     // images and other tenants keep the rest), and a set at most 2^28 slots.
     {
-        const uint64_t bytesPerSlot = 2 * 32 + 2 * 16 + 8 + 16 + 16 + 4 + 16ull * (uint64_t)std::max(1, F.numLights) * std::max<uint32_t>(1, maxB);
+        const LogShape g = log_shape(c, 1u << 20, maxB);      // (shape only: the dense / late split does not depend on the slot count)
+        const uint64_t L = (uint64_t)std::max(1, F.numLights);
+        const uint64_t lateBytes = g.lateBounces ? 4 + ((uint64_t)g.lateBounces * (16 * L + 4) * (uint64_t)std::min(std::max(c->lateLogPercent, 1), 100) + 99) / 100 : 0;
+        const uint64_t bytesPerSlot = 2 * 32 + 2 * 16 + 8 + 16 + 16 + 4 + 16ull * L * g.dense + lateBytes;
         const uint64_t wantSets = (uint64_t)std::min<int>(std::max(1, (int)c->passStreams), rt_ctx::kMaxSets);
         uint64_t slotBudget = std::min<uint64_t>(1ull << 30, (c->deviceBytes / 100 * (uint64_t)std::min(std::max(c->pathMemPercent, 1), 90)) / (wantSets * bytesPerSlot));
         if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
@@ -428,11 +458,14 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         const uint32_t want = (r1 - r0 + (uint32_t)c->passStreams - 1) / (uint32_t)c->passStreams;
         if (want < S_) S_ = std::max<uint32_t>(std::min<uint32_t>(16u, S_), want);
     }
+    // Samples of a pixel per wave (slot_split): 16 (of four pixels) — or all 64 of one pixel where the BVH is far larger than
+    // the L2s: there the traversal kernels gain more from rays that start at one point than k_resolve loses.
+    const int sampleGroup = c->sampleGroup < 0 ? (bvh_bytes(c) > kBigBvhBytes ? 6 : 4) : std::min(c->sampleGroup, 6);
     // Whole sample groups (slot_split: 2^sampleGroup samples of a pixel share a wave), and as many passes as fill the
     // streams evenly: 6 passes on 4 streams leave two streams idle for the last third of the frame.
     {
         const uint32_t n = r1 - r0;
-        uint32_t q = 1u << (uint32_t)std::min(std::max(c->sampleGroup, 0), 6);
+        uint32_t q = 1u << (uint32_t)sampleGroup;
         while (q > 1u && q > S_) q >>= 1;
         S_ -= S_ % q;
         const uint32_t streams = (uint32_t)std::min<int>(std::max(1, (int)c->passStreams), rt_ctx::kMaxSets);
@@ -465,7 +498,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         if (S_ <= 1) return s;
         S_ = std::max(1u, S_ / 2);
     }
-    for (int k = 0; k < nSets; k++) Pset[k] = make_paths(c, k, nslots, sps, lightSlots);
+    for (int k = 0; k < nSets; k++) Pset[k] = make_paths(c, k, nslots, sps, lightSlots, maxB);
     PathBuffers P = Pset[0];
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;
@@ -555,7 +588,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         PathBuffers Pp = P;
         Pp.nslots = inPass * sps;                  // a short last pass uses its own (smaller) log strides
         {   // samples per group of 64 slots (slot_split): the largest power of two <= 2^sampleGroup that divides the pass
-            uint32_t sh = (uint32_t)std::min(std::max(c->sampleGroup, 0), 6);
+            uint32_t sh = (uint32_t)sampleGroup;
             while (sh > 0 && (inPass & ((1u << sh) - 1u)) != 0u) sh--;
             Pp.grpShift = sh;
         }
@@ -590,9 +623,14 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             e = evBegin(1);
             {
                 const bool many = F.numLights > RT_MAX_LIGHTS;
-                auto shadeK = c->anyTextured ? (many ? k_shade<true, true, true, false> : k_shade<true, true, false, false>)
-                            : c->anyTransmissive ? (many ? k_shade<false, true, true, false> : sun1 ? k_shade<false, true, false, true> : k_shade<false, true, false, false>)
-                                                 : (many ? k_shade<false, false, true, false> : sun1 ? k_shade<false, false, false, true> : k_shade<false, false, false, false>);
+                const bool lateLog = Pp.denseBounces < maxB;      // this frame's log has a compact part (log_shape)
+                auto shadeK = lateLog
+                            ? (c->anyTextured ? (many ? k_shade<true, true, true, false, true> : k_shade<true, true, false, false, true>)
+                               : c->anyTransmissive ? (many ? k_shade<false, true, true, false, true> : sun1 ? k_shade<false, true, false, true, true> : k_shade<false, true, false, false, true>)
+                                                    : (many ? k_shade<false, false, true, false, true> : sun1 ? k_shade<false, false, false, true, true> : k_shade<false, false, false, false, true>))
+                            : (c->anyTextured ? (many ? k_shade<true, true, true, false> : k_shade<true, true, false, false>)
+                               : c->anyTransmissive ? (many ? k_shade<false, true, true, false> : sun1 ? k_shade<false, true, false, true> : k_shade<false, true, false, false>)
+                                                    : (many ? k_shade<false, false, true, false> : sun1 ? k_shade<false, false, false, true> : k_shade<false, false, false, false>));
                 shadeK<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(qcount + b), qcount + b + 1,
                                                  scount + b, (int)rBase, (int)b, iAlb, iNor, iDep, pTri, pHit, dst);
             }
@@ -667,6 +705,13 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
 
     DeviceStats hs;
     HIPCHK(c, hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost));
+    if (hs.late_overflow != 0ull && !c->lateLogOff) {
+        // more paths reached a late bounce than the compact part of the log holds: the frame is incomplete.  Render it
+        // again with a dense log, and keep that for this context (a scene whose paths live long).
+        c->lateLogOff = true;
+        c->lateLogFallbacks++;
+        return render_region(c, x, y, w, h, r0, r1);
+    }
     auto t1 = std::chrono::steady_clock::now();
     std::memset(&c->stats, 0, sizeof c->stats);
     c->stats.rays_primary = hs.rays_primary; c->stats.rays_bounce = hs.rays_bounce; c->stats.rays_shadow = hs.rays_shadow;
@@ -711,6 +756,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.launches_pair = nPairs;
     c->stats.wide_nodes = (wide && (refillExtend || refillShadow)) ? 1 : 0;
     c->stats.wide_depth = (int32_t)c->cs.wideDepth;
+    { const LogShape g = log_shape(c, nslots, maxB); c->stats.log_dense_bounces = (int32_t)(g.lateBounces ? g.dense : maxB); c->stats.log_fallbacks = (int32_t)c->lateLogFallbacks; }
     c->stats.kernel_choice = exact ? -2 : combo;
     c->stats.kernel_choice_settled = (exact || c->refill >= 0 || c->kernelChoice >= 0 || c->tuneState >= 4) ? 1 : 0;
     c->primValid = aov;
@@ -845,6 +891,8 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "samplesPerPass")) c->samplesPerPass = v;
     else if (name_is(name, "sampleGroup")) c->sampleGroup = v;
     else if (name_is(name, "pathMemPercent")) c->pathMemPercent = v;
+    else if (name_is(name, "logDenseBounces")) { c->logDenseBounces = v; c->lateLogOff = false; }
+    else if (name_is(name, "lateLogPercent")) { c->lateLogPercent = v; c->lateLogOff = false; }
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
@@ -1020,7 +1068,7 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     if (s) return s;
     uint32_t nslots = (uint32_t)((n + 63) / 64 * 64);
     if ((s = ensure_paths(c, 0, nslots, nslots, 1, 1))) return s;
-    PathBuffers P = make_paths(c, 0, nslots, nslots, 1);
+    PathBuffers P = make_paths(c, 0, nslots, nslots, 1, 1);
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;
     SceneView S = make_view(c, exact);
@@ -1097,6 +1145,7 @@ rt_status rt_trace_rays_noalloc(rt_ctx* c, const float* origins, const float* di
     std::memset(&P, 0, sizeof P);
     P.ray[0] = dRay; P.hit = dHit; P.counters = dCount;
     P.nslots = nslots; P.slotsPerSample = nslots; P.lightSlots = 1; P.grpShift = 0;
+    P.late = nullptr; P.lateNext = nullptr; P.lateHead = nullptr; P.denseBounces = 0xffffffffu; P.lateCap = 0;
     P.overflow = dOv; P.overflowStride = ovStride; P.overflowDepth = ovDepth;
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;

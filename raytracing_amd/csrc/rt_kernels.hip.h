@@ -35,6 +35,13 @@ struct PathBuffers {
     // Indexed by slot (one per sample of the pass and pixel: slot_split), because k_resolve replays them per pixel:
     float4* contrib;     // contribution log [maxBounces][lightSlots][nslots]: rgb, w = 0 none / 1 awaiting shadow ray / 2 add
     uint32_t* depth;     // [nslots] bounces shaded by the slot's path (log entries [0, depth) are valid)
+    // Deep-bounce renders keep only the first `denseBounces` planes of the log per slot; later bounces, which few paths
+    // reach, log at their path's POSITION IN THAT BOUNCE'S QUEUE (lateCap entries per bounce) and a slot finds its entries
+    // through lateHead (its position at bounce denseBounces) and lateNext (from a position to the next bounce's).
+    float4* late;        // [maxBounces - denseBounces][lightSlots][lateCap]
+    uint32_t* lateNext;  // [maxBounces - denseBounces][lateCap]
+    uint32_t* lateHead;  // [nslots]
+    uint32_t denseBounces, lateCap;      // denseBounces >= maxBounces: the whole log is dense
     float4* accum;       // [slotsPerSample] running pixel colour (the shader's `color`), survives passes, shared by all sets
     uint32_t* counters;  // [0..maxB] path-queue sizes per bounce, [maxB+1 .. 2maxB+1] shadow-queue sizes
     uint2* overflow;     // traversal-stack entries beyond the LDS part: entry k of thread g at overflow[k*overflowStride + g]
@@ -46,6 +53,16 @@ struct PathBuffers {
 
 __device__ __forceinline__ void unpack_ray(float4 a, float4 b, v3& o, v3& d, uint32_t& flags, uint32_t& slot) {
     o = mk(a.x, a.y, a.z); d = mk(a.w, b.x, b.y); flags = __float_as_uint(b.z); slot = __float_as_uint(b.w);
+}
+
+// The log entries of one bounce: entry of light l and log index x at base[l * stride + x], where x is the path's slot
+// for a bounce of the dense part and its position in the bounce's queue for a later one.
+struct LogPlane { float4* base; size_t stride; };
+__device__ __forceinline__ LogPlane log_plane(const PathBuffers& P, int bounce) {
+    LogPlane L;
+    if ((uint32_t)bounce < P.denseBounces) { L.base = P.contrib + (size_t)bounce * P.lightSlots * P.nslots; L.stride = P.nslots; }
+    else { L.base = P.late + (size_t)((uint32_t)bounce - P.denseBounces) * P.lightSlots * P.lateCap; L.stride = P.lateCap; }
+    return L;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -592,13 +609,14 @@ __device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float a
 struct ShadeResult { v3 o, d, s; bool refracting, cont, wantShadow; uint32_t pending, skipped; };
 template <bool TEX, bool GLASS, bool MANY, bool SUN1>
 __device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const FrameParams& F, const PathBuffers& P, int bounce, int px, int py, int r,
-                                                  uint32_t slot, float2 h2, v3 rayLoc, v3 rayDir, v3 strength, bool refracting, const v3 hitLoc,
+                                                  uint32_t logIdx, float2 h2, v3 rayLoc, v3 rayDir, v3 strength, bool refracting, const v3 hitLoc,
                                                   float4* imgAlbedo, float4* imgNormal, float4* imgDepth, int32_t* primTri, float* primHit) {
     bool cont = false, wantShadow = false;
     uint32_t pending = 0, skipped = 0;
     int ref = __float_as_int(h2.y);
     v3 camPos = ld3(F.camPos);
-    float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;   // entry of light l at logp[l * nslots]
+    const LogPlane LP = log_plane(P, bounce);
+    float4* logp = LP.base + logIdx;                 // entry of light l at logp[l * LP.stride]
     if (ref == -2) {
         // dead slot (edge tile outside the region)
     } else if (ref < 0) {
@@ -606,7 +624,7 @@ __device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const Fram
         v3 ambient = F.hasSun ? mk(0.4431372549f, 0.73725490196f, 1.f) : mk(0.f, 0.f, 0.f);
         v3 cc = ambient * strength;
         logp[0] = make_float4(cc.x, cc.y, cc.z, 2.f);
-        for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * P.nslots] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * LP.stride] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r == 0 && bounce == 0 && primTri) primTri[(size_t)py * F.width + px] = -1;
     } else {
         const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
@@ -780,7 +798,7 @@ __device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const Fram
                 // cast == false: a light type the shader does not know gets no shadow test and its
                 // contribution (only reachable with a NaN normal) is added directly: w = 2
             } else if (cast) skipped++;
-            logp[(size_t)l * P.nslots] = pendOut;
+            logp[(size_t)l * LP.stride] = pendOut;
         }
 
         // shader.comp:524-530
@@ -801,8 +819,10 @@ __device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const Fram
 // variant with those branches compiled out: fewer live registers on the common path.  MANY: more lights than travel in
 // the kernel arguments (RT_MAX_LIGHTS); otherwise every light is a scalar kernarg read.  SUN1: exactly one light and it is
 // a sun (every BASELINE config): no light loop, no point-light branch.
-template <bool TEX, bool GLASS, bool MANY, bool SUN1>
-__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(SceneView S, FrameParams F, PathBuffers P,
+// LATE: the log has a compact part (PathBuffers::late) and this launch may be one of its bounces; without it that code is
+// compiled out (its few uniform values cost the common variants a wave per SIMD: 135 instead of 125 registers).
+template <bool TEX, bool GLASS, bool MANY, bool SUN1, bool LATE = false>
+__global__ __launch_bounds__(RT_BLOCK, (TEX ? 3 : 4)) void k_shade(SceneView S, FrameParams F, PathBuffers P,
                                                     const uint32_t* __restrict__ count, uint32_t* countOut,
                                                     uint32_t* shadowCountOut, int rBase, int bounce,
                                                     float4* imgAlbedo, float4* imgNormal, float4* imgDepth,
@@ -824,6 +844,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(SceneView S,
     float4* __restrict__ raysOut = P.ray[(bounce + 1) & 1];
     float4* __restrict__ raySOut = P.rayS[(bounce + 1) & 1];
     uint32_t n = *count;
+    // a bounce beyond the dense part of the log: entries at queue positions, of which the log holds lateCap.  A queue longer
+    // than that is cut (the host sees the flag, discards the frame and renders it again with a dense log).
+    const bool lateB = LATE && (uint32_t)bounce >= P.denseBounces;
+    if (lateB && n > P.lateCap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) stats->late_overflow = 1ull;
+        n = P.lateCap;
+    }
+    uint32_t* const lateNext = lateB ? P.lateNext + (size_t)((uint32_t)bounce - P.denseBounces) * P.lateCap : nullptr;
     const uint32_t chunk = RT_BLOCK * RT_ITEMS;
     uint32_t nChunks = (n + chunk - 1) / chunk;
     uint32_t skipped = 0, pending = 0;
@@ -870,8 +898,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(SceneView S,
                 slot_to_pixel(F, ps, &px, &py);
             }
             int ref = __float_as_int(h2.y);
+            const uint32_t logIdx = lateB ? i : slot;
+            if (LATE && (uint32_t)bounce == P.denseBounces) P.lateHead[slot] = i;
             const v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122); only used for hits
-            const ShadeResult R = shade_path<TEX, GLASS, MANY, SUN1>(S, F, P, bounce, px, py, r, slot, h2, rayLoc, rayDir, strength, refracting, hitLoc,
+            const ShadeResult R = shade_path<TEX, GLASS, MANY, SUN1>(S, F, P, bounce, px, py, r, logIdx, h2, rayLoc, rayDir, strength, refracting, hitLoc,
                                                                      imgAlbedo, imgNormal, imgDepth, primTri, primHit);
             rayLoc = R.o; rayDir = R.d; strength = R.s; refracting = R.refracting; cont = R.cont; wantShadow = R.wantShadow;
             pending += R.pending; skipped += R.skipped;
@@ -885,7 +915,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(SceneView S,
 #pragma unroll
                     for (int k = 0; k < RT_ITEMS; k++) if (item == k) slotK[k] = slot;
                 }
-                if (wantShadow && F.anyPoint) P.shadeLoc[slot] = make_float4(hitLoc.x, hitLoc.y, hitLoc.z, 0.f);
+                if (wantShadow && F.anyPoint) P.shadeLoc[logIdx] = make_float4(hitLoc.x, hitLoc.y, hitLoc.z, 0.f);
             }
             // bounces shaded by this slot's path: written once, by the bounce at which the path ends
             if (!cont) P.depth[slot] = ref == -2 ? 0u : (uint32_t)bounce + 1u;
@@ -902,6 +932,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(SceneView S,
       block_append<2>(flag, ctr, idx, ldsAppend);
 #pragma unroll
       for (int k = 0; k < RT_ITEMS; k++) {
+          const uint32_t ik = iBase + (uint32_t)k * RT_BLOCK;
+          if (lateB && ik < n) lateNext[ik] = flag[0][k] ? idx[0][k] : 0xffffffffu;
           if (flag[0][k] | flag[1][k]) {
               const uint32_t st = (uint32_t)k * RT_BLOCK + threadIdx.x;
               const float4 a = stageA[st], b = stageB[st];
@@ -912,7 +944,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(SceneView S,
                   raysOut[2u * o + 1u] = make_float4(b.x, b.y, __uint_as_float(((refrMask >> k) & 1u) ? RT_FLAG_REFRACTING : 0u), sl);
                   raySOut[o] = make_float4(b.z, b.w, stageC[st], 0.f);
               }
-              if (flag[1][k]) P.shadowRec[idx[1][k]] = make_float4(a.x, a.y, a.z, sl);
+              if (flag[1][k]) P.shadowRec[idx[1][k]] = make_float4(a.x, a.y, a.z, lateB ? __uint_as_float(ik) : sl);
           }
       }
     }
@@ -941,7 +973,7 @@ __device__ __forceinline__ void shadow_sun_batch(const SceneView& S, const Frame
     const v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float big = 3.0e38f;
     const bool dPlain = fabsf(d.x) < big && fabsf(d.y) < big && fabsf(d.z) < big && d.x != 0.f && d.y != 0.f && d.z != 0.f;
-    float4* const logBase = P.contrib + (size_t)bounce * P.lightSlots * P.nslots;
+    float4* const logBase = log_plane(P, bounce).base;
     for (uint32_t i = bid * RT_BLOCK + threadIdx.x; i < n; i += nblk * RT_BLOCK) {
         const float4 o4 = P.shadowRec[i];
         const uint32_t slot = __float_as_uint(o4.w);
@@ -1010,12 +1042,13 @@ __device__ __forceinline__ void shadow_batch(const SceneView& S, const FramePara
     uint32_t nNodes = 0, nTris = 0;
     for (uint32_t i = bid * RT_BLOCK + threadIdx.x; i < n; i += nblk * RT_BLOCK) {
         const float4 o4 = P.shadowRec[i];
-        const uint32_t slot = __float_as_uint(o4.w);
+        const uint32_t slot = __float_as_uint(o4.w);      // the path's log index (log_plane): its slot, or its queue position at a late bounce
         v3 o = mk(o4.x, o4.y, o4.z), hitLoc = mk(0.f, 0.f, 0.f);
         if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; hitLoc = mk(h4.x, h4.y, h4.z); }
-        float4* logp = P.contrib + (size_t)bounce * P.lightSlots * P.nslots + slot;
+        const LogPlane LP = log_plane(P, bounce);
+        float4* logp = LP.base + slot;
         for (int l = 0; l < F.numLights; l++) {
-            float* wp = &logp[(size_t)l * P.nslots].w;
+            float* wp = &logp[(size_t)l * LP.stride].w;
             if (F.numLights > 1 && *wp != 1.f) continue;     // (one light: a queued slot always awaits its shadow ray)
             const RefLight Lg = light_at(S, F, l);
             float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, 0.f);
@@ -1064,19 +1097,68 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
 
 // shader.comp:332 and 521: `color.rgb += ...` replayed per pixel in the shader's own order — samples ascending,
 // bounces ascending, lights ascending — from the pass's contribution log.  One thread per pixel slot.
+// The sum itself is a serial chain, but its operands need not arrive one round trip at a time: the depths of RT_RESOLVE_AHEAD
+// samples are fetched together, then (one light: the common case) the first two bounces' entries of all of them, which is
+// where nearly all entries are; deeper bounces are read as the replay reaches them.
+#ifndef RT_RESOLVE_AHEAD
+#define RT_RESOLVE_AHEAD 4
+#endif
+__device__ __forceinline__ void resolve_add(float4& acc, float4 e) {
+    if (e.w == 2.f) { acc.x = acc.x + e.x; acc.y = acc.y + e.y; acc.z = acc.z + e.z; }
+}
+// bounces [b0, d) of the path in `slot`, in order
+__device__ __forceinline__ void resolve_from(const PathBuffers& P, float4& acc, uint32_t slot, uint32_t b0, uint32_t d) {
+    const uint32_t dDense = d < P.denseBounces ? d : P.denseBounces;
+    for (uint32_t b = b0; b < dDense; b++) {
+        const float4* logp = P.contrib + (size_t)b * P.lightSlots * P.nslots + slot;
+        for (uint32_t l = 0; l < P.lightSlots; l++) resolve_add(acc, logp[(size_t)l * P.nslots]);
+    }
+    if (d > dDense) {
+        // the path's later bounces: from its queue position at bounce denseBounces along the chain of next positions
+        // (a position beyond the log only occurs in a frame that overflowed it, which the host discards)
+        uint32_t i = P.lateHead[slot];
+        for (uint32_t b = P.denseBounces; b < d && i < P.lateCap; b++) {
+            const size_t plane = (size_t)(b - P.denseBounces);
+            const uint32_t nxt = P.lateNext[plane * P.lateCap + i];
+            if (b >= b0) {
+                const float4* logp = P.late + plane * P.lightSlots * P.lateCap + i;
+                for (uint32_t l = 0; l < P.lightSlots; l++) resolve_add(acc, logp[(size_t)l * P.lateCap]);
+            }
+            i = nxt;
+        }
+    }
+}
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathBuffers P, int samplesInPass, int maxBounces) {
     uint32_t ps = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (ps >= P.slotsPerSample) return;
     float4 acc = P.accum[ps];
-    for (int sm = 0; sm < samplesInPass; sm++) {
-        uint32_t slot = slot_of(P, (uint32_t)sm, ps);
-        uint32_t d = P.depth[slot];
-        for (uint32_t b = 0; b < d; b++) {
-            const float4* logp = P.contrib + (size_t)b * P.lightSlots * P.nslots + slot;
-            for (uint32_t l = 0; l < P.lightSlots; l++) {
-                float4 e = logp[(size_t)l * P.nslots];
-                if (e.w == 2.f) { acc.x = acc.x + e.x; acc.y = acc.y + e.y; acc.z = acc.z + e.z; }
+    const uint32_t S = (uint32_t)samplesInPass;
+    // (two bounces ahead only where both are planes of the dense part)
+    const bool ahead = P.lightSlots == 1u && P.denseBounces >= 2u && maxBounces >= 2;
+    for (uint32_t sm0 = 0; sm0 < S; sm0 += RT_RESOLVE_AHEAD) {
+        uint32_t slot[RT_RESOLVE_AHEAD], d[RT_RESOLVE_AHEAD];
+#pragma unroll
+        for (int k = 0; k < RT_RESOLVE_AHEAD; k++) {
+            slot[k] = slot_of(P, sm0 + (uint32_t)k < S ? sm0 + (uint32_t)k : S - 1u, ps);
+            d[k] = sm0 + (uint32_t)k < S ? P.depth[slot[k]] : 0u;
+        }
+        if (ahead) {
+            float4 e0[RT_RESOLVE_AHEAD], e1[RT_RESOLVE_AHEAD];
+#pragma unroll
+            for (int k = 0; k < RT_RESOLVE_AHEAD; k++) {
+                e0[k] = make_float4(0.f, 0.f, 0.f, 0.f); e1[k] = e0[k];
+                if (d[k] > 0u) e0[k] = P.contrib[slot[k]];
+                if (d[k] > 1u) e1[k] = P.contrib[(size_t)P.nslots + slot[k]];
             }
+#pragma unroll
+            for (int k = 0; k < RT_RESOLVE_AHEAD; k++) {
+                resolve_add(acc, e0[k]);          // (w = 0 where there is no such bounce: nothing added)
+                resolve_add(acc, e1[k]);
+                if (d[k] > 2u) resolve_from(P, acc, slot[k], 2u, d[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RT_RESOLVE_AHEAD; k++) resolve_from(P, acc, slot[k], 0u, d[k]);
         }
     }
     P.accum[ps] = acc;

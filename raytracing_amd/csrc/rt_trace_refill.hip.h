@@ -434,8 +434,9 @@ __device__ __forceinline__ void shadow_refill(const SceneView& S, const FramePar
                     const uint32_t i = wp.next + pre;
                     const uint32_t q = (L == 1u) ? i : i / L, l = (L == 1u) ? 0u : i % L;
                     const float4 rec = P.shadowRec[q];
-                    const uint32_t slot = __float_as_uint(rec.w);
-                    float* wp_ = &P.contrib[((size_t)bounce * P.lightSlots + l) * P.nslots + slot].w;
+                    const uint32_t slot = __float_as_uint(rec.w);      // the path's log index (log_plane)
+                    const LogPlane LP = log_plane(P, bounce);
+                    float* wp_ = &LP.base[(size_t)l * LP.stride + slot].w;
                     // one light: every queued entry awaits its shadow ray (k_shade queued it for that reason), so the
                     // scattered read of the flag is not needed
                     if (SUN1) {

@@ -169,6 +169,7 @@ struct DeviceStats {
     unsigned long long wave_node_steps, wave_tri_steps;        // wave-level executions of the node / triangle step there
     unsigned long long dbg2[4];
     unsigned long long dbg[8];                                 // instrumented refill kernel: scheduling census (RT_DEBUG=1 prints it)
+    unsigned long long late_overflow;                          // k_shade: a bounce's queue was longer than the compact part of the log holds
 };
 
 }  // namespace rt

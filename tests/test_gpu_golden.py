@@ -27,7 +27,12 @@ VARIANTS = {"culled": {"traversalMode": 0}, "reference_order": {"traversalMode":
             "wide_separate": {"refill": 1, "refillIdle": 1, "fusePairs": 0, "wideNodes": 1},
             # bounce 0 in groups of 64 / 16 / 4 samples of 1 / 4 / 16 pixels per wave instead of one sample of 64 pixels
             "sample_groups_64": {"sampleGroup": 6}, "sample_groups_16_refill": {"sampleGroup": 4, "kernelChoice": 3},
-            "sample_groups_4_spp3": {"sampleGroup": 2, "samplesPerPass": 3}}
+            "sample_groups_4_spp3": {"sampleGroup": 2, "samplesPerPass": 3},
+            # the contribution log in two parts: an entry per slot for the first bounces, per queue position for the later ones
+            "late_log_after_2": {"logDenseBounces": 2, "lateLogPercent": 100}, "late_log_after_1_pairs": {"logDenseBounces": 1, "lateLogPercent": 100, "kernelChoice": 3},
+            "late_log_after_3_batch": {"logDenseBounces": 3, "lateLogPercent": 100, "refill": 0, "fusePairs": 0, "samplesPerPass": 2, "passStreams": 2},
+            # ... and a compact part too small for the frame: the core notices, renders the frame again with a dense log
+            "late_log_overflow": {"logDenseBounces": 1, "lateLogPercent": 1}}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -56,4 +61,10 @@ def test_hip_path_reproduces_golden(models_root, scene, variant):
     assert st["rays_primary"] == rp and st["rays_bounce"] == rb
     # shadow casts the reference issues = traced + skipped (N.L <= 0: the result cannot matter)
     assert st["rays_shadow"] + st["rays_shadow_skipped"] == rs
+    if variant.startswith("late_log"):
+        overflow = variant == "late_log_overflow"
+        assert st["log_fallbacks"] == (1 if overflow else 0), st
+        assert st["log_dense_bounces"] == (b if overflow else VARIANTS[variant]["logDenseBounces"]), st
+    else:
+        assert st["log_dense_bounces"] == b and st["log_fallbacks"] == 0, st      # 8 bounces or fewer: the whole log is dense
     cs.Delete()

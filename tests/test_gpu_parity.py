@@ -190,7 +190,8 @@ MULTI_LIGHTS = [((0.0, 6.75254, 0.0), (0.0, 0.0, 0.0), 0, 10.0),      # (loc, di
                 ((3.0, 2.0, 4.0), (0.0, 0.0, 0.0), 0, 25.0)]
 
 
-@pytest.mark.parametrize("knobs", [{}, {"refill": 1, "refillIdle": 4}, {"traversalMode": 1}, {"samplesPerPass": 2, "passStreams": 3}])
+@pytest.mark.parametrize("knobs", [{}, {"refill": 1, "refillIdle": 4}, {"traversalMode": 1}, {"samplesPerPass": 2, "passStreams": 3},
+                                   {"logDenseBounces": 2, "lateLogPercent": 100}, {"logDenseBounces": 1, "lateLogPercent": 100, "kernelChoice": 3}])
 @pytest.mark.parametrize("scene_id", [3, 4])
 def test_several_lights_bit_exact(oracle_lib, models_root, scene_id, knobs):
     """The reference's light loop (shader.comp:453-522) with more than one light, point and sun mixed — no bundled scene
@@ -217,7 +218,7 @@ def test_several_lights_bit_exact(oracle_lib, models_root, scene_id, knobs):
     cs.Delete()
 
 
-@pytest.mark.parametrize("knobs", [{}, {"refill": 1}])
+@pytest.mark.parametrize("knobs", [{}, {"refill": 1}, {"logDenseBounces": 1, "lateLogPercent": 100}])
 def test_ten_lights_bit_exact(oracle_lib, models_root, knobs):
     """More lights than the copy in the kernel argument segment holds (8): the rest are read from slot 5."""
     from oracle import gltf_flatten as G
