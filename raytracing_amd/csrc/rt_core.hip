@@ -697,11 +697,11 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             const uint32_t tile = std::min(8u, 1u << Pp.grpShift);
             const uint32_t rb = (sps + RT_RESOLVE_BLOCK - 1) / RT_RESOLVE_BLOCK;
             if ((c->resolveTiled > 1 || (c->resolveTiled == 1 && Pp.grpShift == 6u)) && tile >= 2u && lightSlots == 1u && maxB >= 2u && Pp.denseBounces >= 2u) {
-                if (tile == 8u) k_resolve_tiled<8><<<rb, RT_RESOLVE_BLOCK, 0, st>>>(Pp, (int)inPass);
-                else if (tile == 4u) k_resolve_tiled<4><<<rb, RT_RESOLVE_BLOCK, 0, st>>>(Pp, (int)inPass);
-                else k_resolve_tiled<2><<<rb, RT_RESOLVE_BLOCK, 0, st>>>(Pp, (int)inPass);
+                if (tile == 8u) k_resolve_tiled<8><<<rb, RT_RESOLVE_BLOCK, 0, st>>>(Pp, (int)inPass, F.hasSun, F.initialStrength);
+                else if (tile == 4u) k_resolve_tiled<4><<<rb, RT_RESOLVE_BLOCK, 0, st>>>(Pp, (int)inPass, F.hasSun, F.initialStrength);
+                else k_resolve_tiled<2><<<rb, RT_RESOLVE_BLOCK, 0, st>>>(Pp, (int)inPass, F.hasSun, F.initialStrength);
             }
-            else k_resolve<<<pixBlocks, RT_BLOCK, 0, st>>>(Pp, (int)inPass, (int)maxB);
+            else k_resolve<<<pixBlocks, RT_BLOCK, 0, st>>>(Pp, (int)inPass, (int)maxB, F.hasSun, F.initialStrength);
         }
         if (nSets > 1) HIPCHK(c, hipEventRecord(c->evResolve[ks], st));
         passNo++;
