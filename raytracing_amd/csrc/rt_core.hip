@@ -87,7 +87,7 @@ struct rt_ctx {
     float camPos[3] = {0, 0, 0}, camForward[3] = {0, 0, -1}, camRight[3] = {1, 0, 0}, camUp[3] = {0, 1, 0};
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
-    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64, sampleGroup = -1, pathMemPercent = 50, logDenseBounces = 0, lateLogPercent = 25, resolveTiled = 1;
+    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64, sampleGroup = -1, pathMemPercent = 50, logDenseBounces = 0, lateLogPercent = 25;
     uint32_t lateLogFallbacks = 0;
     bool lateLogOff = false;      // a frame overflowed the compact part of the log: this context keeps a dense log from then on
 
@@ -690,19 +690,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         // the pixel sum runs over samples in order (shader.comp:312): this pass's replay follows the previous pass's
         if (nSets > 1 && passNo > 0) HIPCHK(c, hipStreamWaitEvent(st, c->evResolve[(ks + nSets - 1) % nSets], 0));
         // (maxBounces == 0: nothing was shaded, so the per-slot depths k_resolve reads were never written)
-        if (maxB > 0) {
-            // all 64 samples of a pixel adjacent in memory: the tiled replay (whole lines per load; it wants one light and two dense
-            // planes).  With smaller groups the plain kernel's 64-byte pieces do, and the tiled one's LDS competes with k_shade's
-            // and the traversal kernels' for the CU (measured at groups of 16: C2 +11 %, C5 +8 % frame time).
-            const uint32_t tile = std::min(8u, 1u << Pp.grpShift);
-            const uint32_t rb = (sps + RT_RESOLVE_BLOCK - 1) / RT_RESOLVE_BLOCK;
-            if ((c->resolveTiled > 1 || (c->resolveTiled == 1 && Pp.grpShift == 6u)) && tile >= 2u && lightSlots == 1u && maxB >= 2u && Pp.denseBounces >= 2u) {
-                if (tile == 8u) k_resolve_tiled<8><<<rb, RT_RESOLVE_BLOCK, 0, st>>>(Pp, (int)inPass, F.hasSun, F.initialStrength);
-                else if (tile == 4u) k_resolve_tiled<4><<<rb, RT_RESOLVE_BLOCK, 0, st>>>(Pp, (int)inPass, F.hasSun, F.initialStrength);
-                else k_resolve_tiled<2><<<rb, RT_RESOLVE_BLOCK, 0, st>>>(Pp, (int)inPass, F.hasSun, F.initialStrength);
-            }
-            else k_resolve<<<pixBlocks, RT_BLOCK, 0, st>>>(Pp, (int)inPass, (int)maxB, F.hasSun, F.initialStrength);
-        }
+        if (maxB > 0) k_resolve<<<pixBlocks, RT_BLOCK, 0, st>>>(Pp, (int)inPass, (int)maxB, F.hasSun, F.initialStrength);
         if (nSets > 1) HIPCHK(c, hipEventRecord(c->evResolve[ks], st));
         passNo++;
     }
@@ -903,7 +891,6 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "samplesPerPass")) c->samplesPerPass = v;
     else if (name_is(name, "sampleGroup")) c->sampleGroup = v;
     else if (name_is(name, "pathMemPercent")) c->pathMemPercent = v;
-    else if (name_is(name, "resolveTiled")) c->resolveTiled = v;
     else if (name_is(name, "logDenseBounces")) { c->logDenseBounces = v; c->lateLogOff = false; }
     else if (name_is(name, "lateLogPercent")) { c->lateLogPercent = v; c->lateLogOff = false; }
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;

@@ -1179,64 +1179,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathBuffers P, int samples
     P.accum[ps] = acc;
 }
 
-// k_resolve for passes whose slot groups hold T = 2, 4 or 8 samples of a pixel or more (slot_split): a pixel's consecutive
-// samples are then neighbours in memory and neighbouring pixels' are not, so a thread per pixel reading its own entries
-// asks for up to 64 different lines per load.  Here a wave fetches the depths and the first two bounces' entries of a
-// tile of 64 pixels x T samples in memory order (whole lines per wave-level load), parks them in LDS transposed, and then
-// every lane replays its pixel's T samples from there; bounces beyond the second are read as the replay reaches them.
-// One light and at least two dense planes (the host checks; otherwise k_resolve).
-#define RT_RESOLVE_BLOCK 128
-template <int T>
-__global__ __launch_bounds__(RT_RESOLVE_BLOCK) void k_resolve_tiled(PathBuffers P, int samplesInPass, int hasSun, float initialStrength) {
-    constexpr int ROW = T + 1;                                  // padded rows: lanes a row apart fall into different banks
-    __shared__ float4 sE[RT_RESOLVE_BLOCK / 64][2][64 * ROW];
-    __shared__ uint32_t sD[RT_RESOLVE_BLOCK / 64][64 * ROW];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t ps0 = (blockIdx.x * RT_RESOLVE_BLOCK + threadIdx.x) & ~63u;      // the wave's first pixel slot (slotsPerSample is a multiple of 64)
-    if (ps0 >= P.slotsPerSample) return;
-    float4* e0s = sE[wave][0]; float4* e1s = sE[wave][1]; uint32_t* ds = sD[wave];
-    const uint32_t psh = 6u - P.grpShift, pmask = (1u << psh) - 1u;
-    float4 acc = P.accum[ps0 + lane];
-    const float4 miss0 = miss_entry(hasSun, mk(initialStrength, initialStrength, initialStrength));
-    const uint32_t S = (uint32_t)samplesInPass;                 // a multiple of T (rt_core.hip: whole sample groups)
-    for (uint32_t sm0 = 0; sm0 < S; sm0 += T) {
-        // fetch: item m = it * 64 + lane of the tile in memory order -> (pixel pw of the wave, sample qt of the tile)
-        uint32_t slotF[T], dF[T], at[T];
-#pragma unroll
-        for (int it = 0; it < T; it++) {
-            const uint32_t m = (uint32_t)it * 64u + lane;
-            const uint32_t run = (uint32_t)T << psh;            // T samples x the group's pixels: contiguous slots
-            const uint32_t g = m / run, r = m - g * run;        // (run is a power of two)
-            const uint32_t qt = r >> psh, pw = (g << psh) + (r & pmask);
-            slotF[it] = slot_of(P, sm0 + qt, ps0 + pw);
-            at[it] = pw * ROW + qt;
-            dF[it] = P.depth[slotF[it]];
-        }
-#pragma unroll
-        for (int it = 0; it < T; it++) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;  // w = 0: nothing to add
-            if (dF[it] & RT_DEPTH_MISS0) { a = miss0; dF[it] = 1u; }
-            else if (dF[it] > 0u) a = P.contrib[slotF[it]];
-            if (dF[it] > 1u) b = P.contrib[(size_t)P.nslots + slotF[it]];
-            ds[at[it]] = dF[it]; e0s[at[it]] = a; e1s[at[it]] = b;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // replay: lane = pixel
-#pragma unroll
-        for (int qt = 0; qt < T; qt++) {
-            const uint32_t d = ds[lane * ROW + qt];
-            resolve_add(acc, e0s[lane * ROW + qt]);
-            resolve_add(acc, e1s[lane * ROW + qt]);
-            if (d > 2u) resolve_from(P, acc, slot_of(P, sm0 + (uint32_t)qt, ps0 + lane), 2u, d);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                        // the tile is consumed before the next one overwrites it
-    }
-    P.accum[ps0 + lane] = acc;
-}
-
 // Image defaults the shader stores for pixels whose primary ray misses (shader.comp:299-301,534-536).
 __global__ __launch_bounds__(RT_BLOCK) void k_init_frame(FrameParams F, PathBuffers P, float4* imgAlbedo, float4* imgNormal, float4* imgDepth) {
     uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;

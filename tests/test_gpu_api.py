@@ -76,13 +76,12 @@ def test_sample_groups_and_pass_shapes_do_not_change_the_image(oracle_lib, scene
     tri0, hit0 = cs.primary_hits()
     rays0 = [cs.stats()[k] for k in ("rays_primary", "rays_bounce", "rays_shadow", "rays_shadow_skipped")]
     defaults = {"sampleGroup": -1, "samplesPerPass": 64, "passStreams": 0, "autoPass": 1, "pathMemPercent": 50, "kernelChoice": -1,
-                "logDenseBounces": 0, "lateLogPercent": 25, "resolveTiled": 1}
+                "logDenseBounces": 0, "lateLogPercent": 25}
     for knobs in ({"sampleGroup": 0}, {"sampleGroup": 6}, {"sampleGroup": 3, "samplesPerPass": 12}, {"sampleGroup": 2, "samplesPerPass": 4, "passStreams": 3},
                   {"sampleGroup": 6, "samplesPerPass": 5, "autoPass": 0}, {"sampleGroup": 1, "samplesPerPass": 3, "passStreams": 2, "kernelChoice": 3},
                   {"pathMemPercent": 1, "sampleGroup": 2}, {"logDenseBounces": 3, "lateLogPercent": 100, "sampleGroup": 6},
                   {"logDenseBounces": 2, "lateLogPercent": 100, "samplesPerPass": 4, "passStreams": 3},
-                  {"resolveTiled": 2, "sampleGroup": 3, "samplesPerPass": 12}, {"resolveTiled": 2, "sampleGroup": 6, "logDenseBounces": 2, "lateLogPercent": 100},
-                  {"resolveTiled": 0, "sampleGroup": 3, "samplesPerPass": 8}):
+                  {"sampleGroup": 6, "logDenseBounces": 2, "lateLogPercent": 100}):
         for k, v in knobs.items():
             cs.setInt(k, v)
         imgs = _render(cs)

@@ -28,9 +28,6 @@ VARIANTS = {"culled": {"traversalMode": 0}, "reference_order": {"traversalMode":
             # bounce 0 in groups of 64 / 16 / 4 samples of 1 / 4 / 16 pixels per wave instead of one sample of 64 pixels
             "sample_groups_64": {"sampleGroup": 6}, "sample_groups_16_refill": {"sampleGroup": 4, "kernelChoice": 3},
             "sample_groups_4_spp3": {"sampleGroup": 2, "samplesPerPass": 3},
-            # the pixel sums replayed through LDS tiles (k_resolve_tiled, the default for groups of 64) / by the plain kernel
-            "resolve_tiled_4": {"resolveTiled": 2, "sampleGroup": 2, "passStreams": 1}, "resolve_tiled_2": {"resolveTiled": 2, "sampleGroup": 1, "samplesPerPass": 2},
-            "resolve_plain": {"resolveTiled": 0, "sampleGroup": 6},
             # the contribution log in two parts: an entry per slot for the first bounces, per queue position for the later ones
             "late_log_after_2": {"logDenseBounces": 2, "lateLogPercent": 100}, "late_log_after_1_pairs": {"logDenseBounces": 1, "lateLogPercent": 100, "kernelChoice": 3},
             "late_log_after_3_batch": {"logDenseBounces": 3, "lateLogPercent": 100, "refill": 0, "fusePairs": 0, "samplesPerPass": 2, "passStreams": 2},
