@@ -210,6 +210,7 @@ rt_status sync_scene(rt_ctx* c) {
         if (dbgT) std::fprintf(stderr, "[rt] scene sync: compact layout derived in %.3f s, uploaded in %.3f s\n", tSec(tc0, tc1), tSec(tc1, tNow()));
         c->sceneDirty = false;
         c->tuneState = 0; c->tuneChoice = 0;
+        c->lateLogOff = false;      // (a new scene: its paths may be short again)
         c->wideReady = false; c->cs.wnodes.clear(); c->cs.wideDepth = 0;
     }
     if (want_wide(c) && !c->wideReady) {
