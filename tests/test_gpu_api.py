@@ -95,6 +95,30 @@ def test_sample_groups_and_pass_shapes_do_not_change_the_image(oracle_lib, scene
     cs.Delete()
 
 
+def test_camera_moves_between_frames(oracle_lib, scene7):
+    """Three camera positions in a row on one context, each frame equal to the oracle's, then back to the first: nothing
+    derived from the camera is kept across frames."""
+    from raytracing_amd import ComputeShader
+    from tests.util import set_camera
+    from oracle import ref
+    W, H, spp, b = 64, 40, 4, 6
+    cs = ComputeShader()
+    setup_core(cs, scene7, W, H, spp, b)
+    first = None
+    cams = [ref.DEFAULT_CAMERA, ((2.5, 1.5, 4.0), ref.DEFAULT_CAMERA[1]), ((-3.0, 2.0, 3.5), ref.DEFAULT_CAMERA[1]), ref.DEFAULT_CAMERA]
+    for k, cam in enumerate(cams):
+        set_camera(cs, cam, W, H)
+        imgs = _render(cs)
+        want = oracle_lib.render(scene7, oracle_lib.make_params(scene7, W, H, spp, b, math_mode=1, camera=cam))
+        for i, name in enumerate(("color", "albedo", "normal", "depth")):
+            assert same_floats(imgs[i], want[name]).all(), (k, name)
+        if k == 0:
+            first = imgs
+        if k == 3:
+            assert all(same_floats(imgs[i], first[i]).all() for i in range(4))
+    cs.Delete()
+
+
 def test_region_is_bit_identical_and_sample_ranges_sum(oracle_lib, scene4):
     from raytracing_amd import ComputeShader
     W, H, spp, b = 64, 48, 4, 6
