@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="extra rt_set_int tuning knobs (passStreams, refill, refillIdle, refillBlocksPerCU ... see INTEGRATION.md)")
+    ap.add_argument("--dry-run", action="store_true", help="rehearse the launch only: the ranks form the process group (gloo), sum their "
+                    "ranks, rank 0 prints a line with n_gpus and nothing touches a GPU (the CPU test of the launcher path)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -82,6 +84,23 @@ def parse():
             setattr(args, k, wl[k])
     args.desc = wl["desc"]
     return args
+
+
+def binding_units(args, ex):
+    """VALU / texture-addresser busy fractions of the dominant kernel, from the committed counter pass of this workload
+    (profiles/pmc_units_<workload>.json, written by tools/pmc_units.py from rocprofv3 --pmc passes): on a cache-resident
+    scene these units, not L2 or HBM, are what traversal waits for."""
+    path = os.path.join(ROOT, "profiles", "pmc_units_%s.json" % args.workload)
+    if args.overridden or not os.path.exists(path):
+        return {"valu_busy": None, "ta_busy": None}
+    try:
+        j = json.load(open(path))
+        name = "k_extend_refill" if (ex["kernel_choice"] & 1) and ex["kernel_choice"] >= 0 else "k_extend"
+        k = j["kernels"].get(name) or {}
+        return {"valu_busy": k.get("valu_busy"), "ta_busy": k.get("ta_busy"), "waves_per_simd": k.get("waves_per_simd"),
+                "binding_units_source": "profiles/pmc_units_%s.json (%s; %s)" % (args.workload, name, j.get("source", "rocprofv3 --pmc"))}
+    except Exception:
+        return {"valu_busy": None, "ta_busy": None}
 
 
 def cpu_baseline(args, gpu_image):
@@ -117,11 +136,53 @@ def cpu_baseline(args, gpu_image):
                       "reference casts them (incl. shadow casts the GPU path skips)" % (args.scene, W, H, s, args.spp, args.bounces, dt)}
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as the driver's
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` does.  This parent has made
+    no GPU call (torch is not even imported yet), the ranks are child processes, rank 0's JSON line goes straight to our
+    stdout, and we exit with the launcher's status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host driver
+    env["RT_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    seen = 1
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "Mrays/s at 1080p 8-bounce", "value": None, "dry_run": True, "n_gpus": world,
+                          "config": {"rccl_ranks": seen, "backend": "gloo" if world > 1 else None}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # a line that says n_gpus: 1 for a run that was asked for 8 must be impossible
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a mislabeled number\n" % (args.gpus, world))
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     import torch
     if args.share_gpu:
         local = 0
@@ -193,7 +254,9 @@ def main():
         agree_on_kernels(cs)                          # all ranks run what rank 0's trial kept (one broadcast int)
     load_t = dict(load_t)
     load_t["kernel_trial_s"] = round(time.perf_counter() - t_prep, 3)
-    cs.setInt("timeKernels", 0 if args.no_kernel_timing else 1)     # HIP events around every kernel, on the launch stream, live in the timed region
+    # The timed steps carry no instrumentation: per-kernel HIP events are taken on extra frames after the timed region.
+    cs.setInt("timeKernels", 0)
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
     for _ in range(args.warmup):
         step()
     barrier()
@@ -235,9 +298,13 @@ def main():
         # default passStreams = 4) and their kernels overlap, so a launch's event-to-event time there includes the
         # kernels it shares the GPU with.  The roofline wants the kernel by itself: one more frame of the same
         # workload with passStreams = 1, HIP events on the launch stream (both figures are reported).
-        ext_rays = agg["rays_primary"] + agg["rays_bounce"]
-        n_launch = max(1, agg["launches_extend"])
-        overlapped_ms = agg["ms_extend"] / n_launch
+        # (one more frame exactly as the timed ones ran, with events on: what a launch lasts beside the other passes' kernels)
+        ov = {}
+        if not args.no_kernel_timing:
+            cs.setInt("timeKernels", 1)
+            cs.dispatch_region(0, 0, W, H, r0, r1)
+            ov = cs.stats()
+        overlapped_ms = ov.get("ms_extend", 0.0) / max(1, ov.get("launches_extend", 1))
         cs.setInt("timeKernels", 1)
         cs.setInt("passStreams", 1)
         cs.setInt("fusePairs", 0)                    # closest-hit and shadow rays in launches of their own, so that each has a duration
@@ -274,9 +341,10 @@ def main():
                   "alg_bytes_per_launch": round(alg_launch, 1), "alg_rate_GBs": round(achieved, 2),
                   "compact_bvh_bytes": bvh_bytes,
                   "timing": "exclusive: one frame with passStreams=1 and fusePairs=0 after the timed region, HIP events per launch",
-                  "timed_region_avg_launch_ms": round(overlapped_ms, 4),
-                  "timed_region_note": "passes overlap on 4 streams there and the shadow rays of a bounce share a launch with the closest-hit rays of "
-                                       "the next (k_trace_pair), so a launch's duration includes co-running work",
+                  "overlapped_avg_launch_ms": round(overlapped_ms, 4),
+                  "overlapped_note": "one extra frame as the timed ones run (the timed steps themselves carry no events): passes overlap on 4 streams "
+                                     "and the shadow rays of a bounce share a launch with the closest-hit rays of the next (k_trace_pair), so a "
+                                     "launch's duration includes co-running work",
                   "exclusive_kernel_ms_per_frame": {k: round(ex[k], 2) for k in ("ms_extend", "ms_extend_primary", "ms_shade", "ms_shadow")},
                   "alg_bytes_per_ray": round(bytes_per_ray, 1), "avg_launch_ms": round(avg_ms, 4),
                   "launches": ex["launches_extend"], "rays_per_launch": round(ex_rays / ex_launch, 1),
@@ -286,7 +354,8 @@ def main():
                   "bounce_lane_utilisation": {"node_step": round(c["bounce_node_visits"] / max(1, 64 * c["wave_node_steps"]), 3),
                                               "tri_step": round(c["bounce_tri_tests"] / max(1, 64 * c["wave_tri_steps"]), 3),
                                               "wave_node_steps": c["wave_node_steps"], "wave_tri_steps": c["wave_tri_steps"]},
-                  "kernel_ms_per_step": {k: round(agg[k] / args.steps, 2) for k in ("ms_extend", "ms_shade", "ms_shadow")}}
+                  "overlapped_kernel_ms_per_frame": {k: round(ov.get(k, 0.0), 2) for k in ("ms_extend", "ms_shade", "ms_shadow")}}
+        common.update(binding_units(args, ex))
         # Which roof serves the node / triangle fetches of this workload.  A compact BVH that fits the L2s and the Infinity
         # Cache (every bundled scene: <= 13 MB) is never fetched from HBM after the first touch (counter traffic is a few per
         # cent of the algorithmic bytes), so its fetch rate is held against the L2 rate of MI355X_MICROARCH.md, and the
@@ -338,7 +407,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "bundled scene (tests/golden/models), default camera",
             "config": {"workload": "%s %dx%d, %d spp, %d bounces%s"
                                    % (args.desc, W, H, args.spp, args.bounces, "" if headline else " [NOT THE HEADLINE CONFIG]"),
-                       "parallelism": "sample-range x%d, RCCL reduce of the colour buffer" % world if world > 1 else "single GPU",
+                       "parallelism": "sample-range x%d, %s reduce of the colour buffer" % (world, "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else "single GPU",
+                       "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None,
                        "traversal": "culled/ordered (traversalMode 0)",
                        "traversal_kernels": KERNEL_CHOICE.get(last_stats.get("kernel_choice"), "?") +
                                             (" on two-level nodes (128-byte records, %d steps deep)" % last_stats.get("wide_depth", 0) if last_stats.get("wide_nodes") else "") +

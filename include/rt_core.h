@@ -180,8 +180,9 @@ rt_status rt_read_primary_hits(rt_ctx* ctx, int32_t* tri_ids, float* hit_locs);
 rt_status rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint64_t n,
                         int32_t* tri_ids, float* hit_locs);
 
-/* rt_trace_rays for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc.  No counterpart in the reference.  Same arguments, same kernels and bit-identical results, but the
+/* rt_trace_rays for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc, code that must
+ * not disturb the device heap.  No counterpart in the reference.  (Not capturable into a HIP graph as it stands: it copies
+ * from / to pageable host memory and synchronises the context's stream before it returns, also on its error paths.)  Same arguments, same kernels and bit-identical results, but the
  * ray queue, hit records, queue counter, traversal-stack overflow and the staged inputs / outputs live in a file-scope
  * device array of the library (about 8.4 MB, held by every GPU the library runs on until the process ends) instead of
  * hipMalloc'ed buffers, and the call makes no hipMalloc / hipFree / allocating library call.  Limits: n <=

@@ -274,6 +274,14 @@ std::vector<mat4> Model::getMatricesMeshes() {
     return out;
 }
 
+// SSBO::Bind takes a 32-bit size as the reference's does (SSBO.h:9: GLuint).  The reference would wrap silently above
+// 4 GiB (33.5 M triangles) and upload a short buffer; the mirror refuses instead (the C ABI itself takes 64 bits).
+static uint32_t ssbo_size(size_t bytes, const char* what) {
+    if (bytes > 0xffffffffull)
+        throw std::length_error(std::string(what) + " buffer is " + std::to_string(bytes) + " bytes: more than SSBO::Bind's 32-bit size holds (SSBO.h:9)");
+    return (uint32_t)bytes;
+}
+
 // model.cpp:532-613
 std::vector<GPUBoundingBox> Model::BVH() {
     auto t0 = std::chrono::steady_clock::now();
@@ -331,11 +339,11 @@ std::vector<GPUBoundingBox> Model::BVH() {
     auto t1 = std::chrono::steady_clock::now();
     std::vector<GPUBoundingBox> BVHList = build_bvh(triangles.data(), triangles.size(), 0, /*allowGpu=*/!g_dry);   // a dry run (no context) stays on the host
     auto t2 = std::chrono::steady_clock::now();
-    SSBO::Bind(verticesList.data(), (uint32_t)(verticesList.size() * sizeof(Vertex)), 0);
-    SSBO::Bind(meshMatrices.data(), (uint32_t)(meshMatrices.size() * sizeof(mat4)), 1);
-    SSBO::Bind(materialList.data(), (uint32_t)(materialList.size() * sizeof(MaterialData)), 2);
-    SSBO::Bind(BVHList.data(), (uint32_t)(BVHList.size() * sizeof(GPUBoundingBox)), 3);
-    SSBO::Bind(triangles.data(), (uint32_t)(triangles.size() * sizeof(Triangle)), 4);
+    SSBO::Bind(verticesList.data(), ssbo_size(verticesList.size() * sizeof(Vertex), "vertex"), 0);
+    SSBO::Bind(meshMatrices.data(), ssbo_size(meshMatrices.size() * sizeof(mat4), "mesh-matrix"), 1);
+    SSBO::Bind(materialList.data(), ssbo_size(materialList.size() * sizeof(MaterialData), "material"), 2);
+    SSBO::Bind(BVHList.data(), ssbo_size(BVHList.size() * sizeof(GPUBoundingBox), "BVH-node"), 3);
+    SSBO::Bind(triangles.data(), ssbo_size(triangles.size() * sizeof(Triangle), "triangle"), 4);
     auto t3 = std::chrono::steady_clock::now();
     lastFlattenSeconds = std::chrono::duration<double>(t1 - t0).count();
     lastBuildSeconds = std::chrono::duration<double>(t2 - t1).count();
@@ -400,7 +408,7 @@ void Scene::LoadGPUData(ComputeShader* computeShader) {
     std::vector<GPUBoundingBox> BVHList = Model::BVH();
     bool hasSun;
     std::vector<GPULight> lights = Light::ToGPU(hasSun);
-    SSBO::Bind(lights.data(), (uint32_t)(lights.size() * sizeof(GPULight)), 5);
+    SSBO::Bind(lights.data(), ssbo_size(lights.size() * sizeof(GPULight), "light"), 5);
     computeShader->setInt("numLights", (int)lights.size());
     computeShader->setInt("hasSun", hasSun);
     // Scene.cpp:79-84 creates one GL wireframe Box per BVH node for a debug overlay: dropped (no GL).

@@ -135,6 +135,7 @@ struct State {
     float* dTileCost = nullptr; int* dTileIndex = nullptr;
     std::vector<float> hCost; std::vector<int> hIndex;
     bool ok = false;
+    bool busy = false;             // a build owns the device state from begin() to end(); a second build at that time sweeps on the host
 };
 inline State& state() { static State s; return s; }
 
@@ -147,10 +148,13 @@ inline void release_all(State& s) {
     s.cap = 0; s.ok = false;
 }
 
-// Makes the scene's triangle bounds resident on the current device.  false: no device / no memory — the host sweeps then.
+// Makes the scene's triangle bounds resident on the device that is current in the calling (loader) thread.  false: no
+// device / no memory / another build (another thread or context of this process) holds the state — the host sweeps then,
+// with the same results.  One build at a time owns the state: begin() .. end() bracket it.
 inline bool begin(const B6* boxes, size_t n) {
     State& s = state();
     std::lock_guard<std::mutex> g(s.mu);
+    if (s.busy) return false;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return false; }
     if (hipGetDevice(&s.device) != hipSuccess) return false;
@@ -163,7 +167,7 @@ inline bool begin(const B6* boxes, size_t n) {
     ok = ok && hipMemcpy(s.dBoxes, boxes, n * sizeof(Box), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); release_all(s); return false; }
     s.hCost.resize(tiles); s.hIndex.resize(tiles);
-    s.cap = n; s.ok = true;
+    s.cap = n; s.ok = true; s.busy = true;
     return true;
 }
 
@@ -196,6 +200,7 @@ inline void end() {
     std::lock_guard<std::mutex> g(s.mu);
     if (s.device >= 0) (void)hipSetDevice(s.device);
     release_all(s);
+    s.busy = false;
 }
 
 struct Registrar {

@@ -435,6 +435,10 @@ static inline void fill_shade_uv(const RefVertex* verts, const RefTriangle* rtri
 // leaves out.wnodes empty — when the tree does not qualify: its root is a leaf, its boxes are not nested (an uploaded
 // tree that is not the reference builder's: skipping a level would then skip a test the reference makes), its boxes do not
 // contain their triangles, or it is so deep that three pending siblings per wide level could outgrow the 64-entry stack.
+// (boxesContainTris is checked for EVERY internal reference node against the world bounds of all triangles below it
+// (Walk::run, state 2), not only leaf box against triangles: a leaf two levels down whose triangles reach outside the box of
+// the internal child above it clears the flag, so the clipping of such a leaf's slot to that box never culls a hit the
+// reference reports — such a tree takes the reference-order walk altogether; test_two_level_nodes_only_for_trees_that_qualify.)
 static inline bool derive_wide(CompactScene& out) {
     out.wnodes.clear(); out.wideDepth = 0;
     if (out.rootChild < 0 || out.nodes.empty() || !out.boxesContainTris) return false;

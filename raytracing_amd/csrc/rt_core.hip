@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/rt_core.h"
@@ -41,6 +43,8 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 // once per device (rt_create, with that device current) and only these pointers are ever handed to kernels and copies.
 constexpr int kMaxDevices = 64;
 unsigned char* g_scratchPtr[kMaxDevices] = {};
+std::once_flag g_scratchOnce[kMaxDevices];      // two threads creating contexts on one device look the address up once
+hipError_t g_scratchErr[kMaxDevices] = {};
 
 }  // namespace
 
@@ -125,6 +129,8 @@ struct rt_ctx {
     uint64_t allocations = 0;   // hipMalloc calls so far (a frame that allocated is not a timing sample)
     int tuneState = 0;          // 0..3: the next sizeable frame samples combination kTuneTrial[tuneState]; 4: decided
     double tuneRate[4] = {0.0, 0.0, 0.0, 0.0};
+    uint64_t sceneKey = 0;      // content key of the scene on the device (scene_key): the trial's result is remembered under it
+    int32_t tuneCache = 1;      // 0: always run the trial (knob)
     int tuneChoice = 0;         // bit 0: refill kernel for closest-hit rays, bit 1: for shadow rays
     int32_t kernelChoice = -1;  // >= 0: this combination (bit 0 / bit 1 as tuneChoice) whatever was measured: every rank of a
                                 // multi-GPU job is given rank 0's choice, so that shards cost the same everywhere
@@ -147,6 +153,11 @@ struct rt_ctx {
 namespace {
 
 thread_local std::string g_createErr;
+
+// What the per-scene kernel trial kept, by scene content and device: a scene that comes back (the reference's interactive
+// scene switching, main.cpp:308-321; a second context on the same GPU) skips the four trial frames.  Process-wide.
+struct TuneCache { std::mutex mu; std::unordered_map<uint64_t, int> choice; };
+TuneCache& tune_cache() { static TuneCache t; return t; }
 
 rt_status fail(rt_ctx* c, rt_status s, const std::string& m) { if (c) c->err = m; else g_createErr = m; return s; }
 
@@ -181,6 +192,21 @@ constexpr size_t kBigBvhBytes = (size_t)64 << 20;
 size_t bvh_bytes(const rt_ctx* c) { return c->cs.nodes.size() * sizeof(CNode) + (size_t)c->cs.nTris * sizeof(CTri); }
 bool want_wide(const rt_ctx* c) { return c->wideNodes > 0 || (c->wideNodes < 0 && bvh_bytes(c) > kBigBvhBytes); }
 
+// FNV-1a over the sizes of slots 0..4 and up to 256 evenly spaced 64-byte samples of the node and triangle buffers
+uint64_t scene_key(const rt_ctx* c) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    const int32_t dev = c->device;
+    mix(&dev, sizeof dev);
+    for (int s = 0; s < 5; s++) { const uint64_t n = c->slotHost[s].size(); mix(&n, sizeof n); }
+    for (int s : {RT_SLOT_BVH_NODES, RT_SLOT_TRIANGLES}) {
+        const auto& B = c->slotHost[s];
+        const size_t chunks = B.size() / 64, step = std::max<size_t>(1, chunks / 256);
+        for (size_t k = 0; k < chunks; k += step) mix(B.data() + k * 64, 64);
+    }
+    return h;
+}
+
 rt_status sync_scene(rt_ctx* c) {
     for (int s = 0; s < 6; s++)
         if (!c->slotSet[s]) return fail(c, RT_ERR_NOT_READY, "slot " + std::to_string(s) + " has not been uploaded");
@@ -210,6 +236,13 @@ rt_status sync_scene(rt_ctx* c) {
         if (dbgT) std::fprintf(stderr, "[rt] scene sync: compact layout derived in %.3f s, uploaded in %.3f s\n", tSec(tc0, tc1), tSec(tc1, tNow()));
         c->sceneDirty = false;
         c->tuneState = 0; c->tuneChoice = 0;
+        c->sceneKey = scene_key(c);
+        if (c->tuneCache != 0) {
+            TuneCache& T = tune_cache();
+            std::lock_guard<std::mutex> g(T.mu);
+            auto it = T.choice.find(c->sceneKey);
+            if (it != T.choice.end()) { c->tuneState = 4; c->tuneChoice = it->second; }
+        }
         c->lateLogOff = false;      // (a new scene: its paths may be short again)
         c->wideReady = false; c->cs.wnodes.clear(); c->cs.wideDepth = 0;
     }
@@ -730,6 +763,11 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                 for (int t = 0; t < 4; t++) if (c->tuneRate[t] > c->tuneRate[best]) best = t;
                 if (c->tuneRate[best] <= 1.015 * c->tuneRate[defTrial]) best = defTrial;
                 c->tuneChoice = kTuneTrial[best];
+                if (c->tuneCache != 0) {
+                    TuneCache& T = tune_cache();
+                    std::lock_guard<std::mutex> g(T.mu);
+                    T.choice[c->sceneKey] = c->tuneChoice;
+                }
             }
         }
     }
@@ -758,7 +796,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.wide_nodes = (wide && (refillExtend || refillShadow)) ? 1 : 0;
     c->stats.wide_depth = (int32_t)c->cs.wideDepth;
     { const LogShape g = log_shape(c, nslots, maxB); c->stats.log_dense_bounces = (int32_t)(g.lateBounces ? g.dense : maxB); c->stats.log_fallbacks = (int32_t)c->lateLogFallbacks; }
-    c->stats.kernel_choice = exact ? -2 : combo;
+    // the combination the NEXT frame will run: on the frame that finishes the trial `combo` is still the last trial's
+    c->stats.kernel_choice = exact ? -2 : (trial && c->tuneState >= 4) ? c->tuneChoice : combo;
     c->stats.kernel_choice_settled = (exact || c->refill >= 0 || c->kernelChoice >= 0 || c->tuneState >= 4) ? 1 : 0;
     c->primValid = aov;
     return RT_OK;
@@ -822,12 +861,15 @@ rt_status rt_create(rt_ctx** out, const rt_config* cfg) {
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available (librt_core has no CPU fallback)");
     if (dev < 0 || dev >= ndev) return fail(nullptr, RT_ERR_NO_DEVICE, "device ordinal out of range");
     if (hipSetDevice(dev) != hipSuccess) return fail(nullptr, RT_ERR_NO_DEVICE, "hipSetDevice failed");
-    if (dev < kMaxDevices && !g_scratchPtr[dev]) {
-        // this device's copy of the file-scope scratch array (rt_trace_rays_noalloc), looked up with the device current
-        void* sp = nullptr;
-        hipError_t se = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
-        if (se != hipSuccess || !sp) return fail(nullptr, RT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se));
-        g_scratchPtr[dev] = (unsigned char*)sp;
+    if (dev < kMaxDevices) {
+        // this device's copy of the file-scope scratch array (rt_trace_rays_noalloc), looked up once, with the device current
+        // (every caller has just made `dev` current on its own thread, so whichever thread runs the lookup has too)
+        std::call_once(g_scratchOnce[dev], [dev] {
+            void* sp = nullptr;
+            g_scratchErr[dev] = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+            if (g_scratchErr[dev] == hipSuccess) g_scratchPtr[dev] = (unsigned char*)sp;
+        });
+        if (!g_scratchPtr[dev]) return fail(nullptr, RT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(g_scratchErr[dev]));
     }
     rt_ctx* c = new rt_ctx();
     c->device = dev;
@@ -903,6 +945,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "refillDefer")) c->refillDefer = v;
     else if (name_is(name, "wideNodes")) c->wideNodes = v;
     else if (name_is(name, "sunKernel")) c->sunKernel = v;
+    else if (name_is(name, "tuneCache")) c->tuneCache = v;
     else if (name_is(name, "kernelChoice")) c->kernelChoice = v < 0 ? -1 : (v & 3);
     else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 0 ? 0 : v;
     else if (name_is(name, "autoPass")) c->autoPass = v;
@@ -1154,20 +1197,30 @@ rt_status rt_trace_rays_noalloc(rt_ctx* c, const float* origins, const float* di
     hipStream_t st = c->stream;
     // the array keeps the previous call's contents: the header (queue counter, statistics) starts at zero; everything else
     // a call reads it has written first (rays, hits and results for i < n; stack entries are pushed before they are popped)
-    HIPCHK(c, hipMemsetAsync(base, 0, kScratchHeader, st));
-    HIPCHK(c, hipMemcpyAsync(dO, origins, 12ull * nn, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(dD, dirs, 12ull * nn, hipMemcpyHostToDevice, st));
-    k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, dO, dD, nn, dCount);
-    FrameParams F0;
-    std::memset(&F0, 0, sizeof F0);
-    launch_extend<false>(exact, count, dim3(blocks), st, S, F0, P, (const float4*)dRay, (const uint32_t*)dCount, 0, 0u, dst);
-    k_hits_out<<<(nn + 255u) / 256u, 256, 0, st>>>(dHit, dO, dD, nn, dTri, dLoc);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(tri, dTri, 4ull * nn, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hits, dLoc, 12ull * nn, hipMemcpyDeviceToHost, st));
+    // From here on work is in flight on the shared array: an error return drains the stream first, so that the next call on
+    // this GPU cannot overlap what this one left running.
     DeviceStats hs;
-    HIPCHK(c, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    hipError_t e = hipMemsetAsync(base, 0, kScratchHeader, st);
+    const char* what = "hipMemsetAsync(header)";
+    auto step = [&](hipError_t r, const char* w) { if (e == hipSuccess && r != hipSuccess) { e = r; what = w; } return e == hipSuccess; };
+    if (e == hipSuccess) step(hipMemcpyAsync(dO, origins, 12ull * nn, hipMemcpyHostToDevice, st), "copy of origins");
+    if (e == hipSuccess) step(hipMemcpyAsync(dD, dirs, 12ull * nn, hipMemcpyHostToDevice, st), "copy of dirs");
+    if (e == hipSuccess) {
+        k_load_rays<<<blocks, RT_BLOCK, 0, st>>>(P, dO, dD, nn, dCount);
+        FrameParams F0;
+        std::memset(&F0, 0, sizeof F0);
+        launch_extend<false>(exact, count, dim3(blocks), st, S, F0, P, (const float4*)dRay, (const uint32_t*)dCount, 0, 0u, dst);
+        k_hits_out<<<(nn + 255u) / 256u, 256, 0, st>>>(dHit, dO, dD, nn, dTri, dLoc);
+        step(hipGetLastError(), "kernel launch");
+    }
+    if (e == hipSuccess) step(hipMemcpyAsync(tri, dTri, 4ull * nn, hipMemcpyDeviceToHost, st), "copy of tri_ids");
+    if (e == hipSuccess) step(hipMemcpyAsync(hits, dLoc, 12ull * nn, hipMemcpyDeviceToHost, st), "copy of hit_locs");
+    if (e == hipSuccess) step(hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, st), "copy of statistics");
+    {
+        const hipError_t se = hipStreamSynchronize(st);      // always: the call returns with nothing of its own in flight
+        if (e == hipSuccess && se != hipSuccess) { e = se; what = "hipStreamSynchronize"; }
+    }
+    if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("rt_trace_rays_noalloc: ") + what + ": " + hipGetErrorString(e));
     std::memset(&c->stats, 0, sizeof c->stats);
     c->stats.rays_primary = hs.rays_primary + hs.rays_bounce; c->stats.node_visits = hs.node_visits; c->stats.tri_tests = hs.tri_tests;
     return RT_OK;

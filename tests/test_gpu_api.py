@@ -476,3 +476,49 @@ def test_contexts_release_their_device_memory(scene4):
     for _ in range(12):
         one_round()
     assert free_bytes() >= before - (64 << 20)      # allocator granularity, not a per-round loss
+
+
+def test_settled_kernel_choice_is_what_the_next_frame_runs(scene4):
+    """on the frame that finishes the per-scene trial, rt_stats must name the combination the trial kept (what the
+    NEXT frame runs), not the last trial's own combination — distributed.agree_on_kernels pins exactly that number on every
+    rank.  Frames of 1280 x 720 x 16 samples (>= 1e7 samples, >= 3e7 rays) qualify as trial frames."""
+    from raytracing_amd import ComputeShader
+    cs = ComputeShader()
+    setup_core(cs, scene4, 1280, 720, 16, 8)
+    cs.setInt("tuneCache", 0)                              # (an earlier test of this process may have settled this scene already)
+    seen = []
+    for _ in range(8):
+        cs.dispatch()
+        st = cs.stats()
+        seen.append((st["kernel_choice"], st["kernel_choice_settled"]))
+    settled = [i for i, (_, s) in enumerate(seen) if s]
+    assert settled, seen                                   # the trial finishes within a few frames
+    first = settled[0]
+    assert first >= 4, seen                                # four trial frames (frame 0 allocates and does not count)
+    assert all(s for _, s in seen[first:]), seen
+    assert len({c for c, _ in seen[first:]}) == 1, seen    # the settling frame already reports the kept choice
+    # pinned by a knob: reported as settled at once
+    cs.setInt("kernelChoice", 2)
+    cs.dispatch()
+    st = cs.stats()
+    assert (st["kernel_choice"], st["kernel_choice_settled"]) == (2, 1)
+    cs.Delete()
+
+
+def test_a_scene_that_comes_back_skips_the_kernel_trial(scene4):
+    """The trial's result is remembered per scene content (knob tuneCache): a second context that loads the same scene is
+    settled from its first frame on, with the same choice."""
+    from raytracing_amd import ComputeShader
+    a = ComputeShader()
+    setup_core(a, scene4, 1280, 720, 16, 8)
+    for _ in range(6):
+        a.dispatch()
+    sa = a.stats()
+    assert sa["kernel_choice_settled"] == 1
+    b = ComputeShader()
+    setup_core(b, scene4, 1280, 720, 16, 8)
+    b.dispatch()
+    sb = b.stats()
+    assert (sb["kernel_choice"], sb["kernel_choice_settled"]) == (sa["kernel_choice"], 1)
+    a.Delete()
+    b.Delete()

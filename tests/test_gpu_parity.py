@@ -464,8 +464,16 @@ def test_two_level_nodes_only_for_trees_that_qualify(oracle_lib):
         # internal node 6, wider than the node above it — whose own test a two-level step starting at node 4 would skip
         nodes[2 * 6]["minLoc"], nodes[2 * 6]["maxLoc"] = (-7, -1, -1), (7, 9, 1)
 
+    def leaf_pokes_out(nodes):
+        # internal nodes 6.. start above the first row of triangles: triangles 6..9 — leaves two levels below the wide
+        # node that would hold them — reach outside the box of the internal child above them (boxes stay nested).  A ray
+        # can pass that box and hit the triangle outside it; a slot clipped to the box would lose that hit.  The core
+        # sees that a box does not contain what it leads to and walks the tree in the reference's order instead.
+        for k in range(6, 39):
+            nodes[2 * k]["minLoc"] = (-6, 0.9, -1)
+
     cs = ComputeShader()
-    for n, tweak, wide, depth in ((40, None, 1, 20), (50, None, 0, 0), (40, not_nested, 0, 0)):
+    for n, tweak, wide, depth, choice in ((40, None, 1, 20, 3), (50, None, 0, 0, 3), (40, not_nested, 0, 0, 3), (40, leaf_pokes_out, 0, 0, -2)):
         sc = _chain_scene(oracle_lib, n, tweak)
         want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
         setup_core(cs, sc, W, H, spp, b)
@@ -474,7 +482,7 @@ def test_two_level_nodes_only_for_trees_that_qualify(oracle_lib):
         cs.dispatch()
         st = cs.stats()
         assert (st["wide_nodes"], st["wide_depth"]) == (wide, depth), (n, st["wide_nodes"], st["wide_depth"])
-        assert st["kernel_choice"] == 3
+        assert st["kernel_choice"] == choice
         for k, name in enumerate(("color", "albedo", "normal", "depth")):
             assert same_floats(cs.get_image(k), want[name]).all(), (n, name)
         assert np.array_equal(cs.primary_hits()[0], want["prim_tri"])
@@ -496,6 +504,28 @@ def test_headline_sample_count_bit_exact(oracle_lib, scenes, scene_id, bounces):
     for k, name in enumerate(("color", "albedo", "normal", "depth")):
         bad = ~same_floats(cs.get_image(k), want[name])
         assert not bad.any(), "%s: %d floats differ" % (name, int(bad.sum()))
+    st, ost = cs.stats(), want["stats"]
+    assert st["rays_primary"] == ost["rays_primary"] == W * H * spp
+    assert st["rays_bounce"] == ost["rays_bounce"]
+    assert st["rays_shadow"] + st["rays_shadow_skipped"] == ost["rays_shadow"]
+    cs.Delete()
+
+
+def test_config1_whole_frame_bit_exact(oracle_lib, scenes):
+    """BASELINE configs[0] itself, not a reduced version of it: scene 3 (box + roughSphere, textured floor, point light),
+    512 x 512, 64 spp, 8 bounces — the one benchmark frame the oracle renders whole in a few seconds.  All four images, the
+    primary-hit ids and the ray counts."""
+    from raytracing_amd import ComputeShader
+    sc = scenes(3)
+    W, H, spp, b = 512, 512, 64, 8
+    want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, b)
+    cs.dispatch()
+    for k, name in enumerate(("color", "albedo", "normal", "depth")):
+        bad = ~same_floats(cs.get_image(k), want[name])
+        assert not bad.any(), "%s: %d floats differ" % (name, int(bad.sum()))
+    assert np.array_equal(cs.primary_hits()[0], want["prim_tri"])
     st, ost = cs.stats(), want["stats"]
     assert st["rays_primary"] == ost["rays_primary"] == W * H * spp
     assert st["rays_bounce"] == ost["rays_bounce"]
