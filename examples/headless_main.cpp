@@ -3,12 +3,16 @@
 // raytracing_amd/csrc/host/rt_host.hpp over the C ABI of include/rt_core.h.  No window, no GL: what the reference
 // draws to the screen is read back with rt_read_image (= glGetTexImage) and the frames go to PPM files.
 //
-//   headless_main <models_root> [scene=2] [width=800] [height=600] [spp=100] [bounces=10] [frames=1] [out_dir=Renders]
+//   headless_main <models_root> [scene=2] [width=800] [height=600] [spp=100] [bounces=10] [frames=1] [out_dir=Renders] [gpus=1]
+//
+// gpus > 1: the same loop on rt_host::MultiGPU — one context and one host thread per GPU, every frame split into sample
+// ranges, one RCCL reduce of the colour image onto GPU 0 (no reference counterpart: the reference is single-GPU).
 //
 // The defaults are the reference's own hard-coded ones (main.h:35, main.cpp:241-244).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -18,13 +22,50 @@
 using namespace rt_host;
 
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s <models_root> [scene width height spp bounces frames out_dir]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <models_root> [scene width height spp bounces frames out_dir gpus]\n", argv[0]); return 2; }
     const std::string models = argv[1];
     const int scene = argc > 2 ? std::atoi(argv[2]) : 2;
     const int width = argc > 3 ? std::atoi(argv[3]) : 800, height = argc > 4 ? std::atoi(argv[4]) : 600;
     const int spp = argc > 5 ? std::atoi(argv[5]) : 100, bounces = argc > 6 ? std::atoi(argv[6]) : 10;
     const int frames = argc > 7 ? std::atoi(argv[7]) : 1;
     const std::string outDir = argc > 8 ? argv[8] : "Renders";
+    const bool devList = argc > 9 && std::string(argv[9]).find(',') != std::string::npos;
+    const int gpus = argc > 9 ? std::atoi(argv[9]) : 1;
+    if (gpus > 1 || devList) {
+        // (a comma-separated list of ordinals instead of a count — "0,0" — puts several contexts on one GPU: a rehearsal)
+        std::vector<int> devs;
+        const std::string a = argv[9];
+        if (devList) { size_t p = 0; while (p <= a.size()) { size_t q = a.find(',', p); if (q == std::string::npos) q = a.size(); devs.push_back(std::atoi(a.substr(p, q - p).c_str())); p = q + 1; } }
+        else for (int d = 0; d < gpus; d++) devs.push_back(d);
+        try {
+            MultiGPU multi(devs);
+            Camera camera(width, height, vec3(0.0f, 3.5f, 14.0f));
+            Scene::modelsRoot = models;
+            Scene::currSceneIndex = 0;
+            Scene::LoadScene(multi.shader(0), scene);
+            multi.ReplicateScene();
+            multi.setInt("maxBounces", bounces);
+            multi.resize((uint32_t)width, (uint32_t)height);
+            if (frames > 1) Renderer::Start(width, height, spp, bounces, outDir);
+            for (int f = 0; f < frames; f++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                multi.SetFrameUniforms(&camera, vec2{(float)width, (float)height});
+                multi.RenderFrame((uint32_t)spp);
+                double rays = 0;
+                for (size_t i = 0; i < multi.size(); i++) { rt_stats st; rt_get_stats(multi.shader(i)->ID, &st); rays += (double)(st.rays_primary + st.rays_bounce + st.rays_shadow); }
+                const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                std::printf("frame %d: %.1f ms, %.0f Mrays/s on %zu contexts%s\n", f, s * 1e3, rays / s / 1e6, multi.size(), multi.usedRccl() ? " (RCCL reduce)" : "");
+                if (Renderer::isRenderering()) Renderer::NextFrame(multi.shader(0), (uint32_t)width, (uint32_t)height, &camera);
+            }
+            std::vector<float> rgba((size_t)width * height * 4);
+            if (rt_read_image(multi.shader(0)->ID, RT_IMAGE_COLOR, rgba.data()) != RT_OK) return 1;
+            double sum = 0;
+            for (size_t i = 0; i < rgba.size(); i += 4) sum += rgba[i] + rgba[i + 1] + rgba[i + 2];
+            std::printf("mean radiance of the last frame: %.6f\n", sum / (3.0 * width * height));
+            Scene::UnloadScene();
+        } catch (const std::exception& e) { std::fprintf(stderr, "multi-GPU render failed: %s\n", e.what()); return 1; }
+        return 0;
+    }
 
     // Main::Start (main.cpp:230-247)
     ComputeShader computeShader("shader.comp");

@@ -135,6 +135,11 @@ rt_status rt_read_frame_rgba8(rt_ctx* ctx, uint8_t* dst_rgba8, uint64_t dst_byte
  * device-side denoisers).  No reference counterpart. */
 rt_status rt_image_device_ptr(rt_ctx* ctx, uint32_t image, void** dev_ptr);
 
+/* dst image += an image of the same size that lives on the SAME GPU (another context's rt_image_device_ptr): the merge step
+ * of partial renders (row bands / sample ranges, rt_render_region) when two contexts share one GPU.  Across GPUs the merge
+ * is the RCCL reduce (rt_host.h, rth_multi_render_frame).  No reference counterpart. */
+rt_status rt_add_image(rt_ctx* ctx, uint32_t image, const void* src_dev_ptr);
+
 /* Counters of the last rt_render_* call (no reference counterpart; feeds the Mrays/s metric). */
 typedef struct rt_stats {
     uint64_t rays_primary;     /* lineCast calls at bounce 0                                   */

@@ -61,6 +61,36 @@ rt_status rth_frame_rgba8(rt_ctx* ctx, uint32_t width, uint32_t height, uint8_t*
 rt_status rth_decode_image(const char* path, uint8_t** rgba8_out, uint32_t* w, uint32_t* h);
 rt_status rth_decode_png(const char* path, uint8_t** rgba8_out, uint32_t* w, uint32_t* h);
 
+/* ---- Multi-GPU frame driver (no reference counterpart: the reference is single-GPU, one GL context) --------------------
+ * The frame loop of main.cpp:106-141 / Renderer.cpp:91-193 on N GPUs of one node from ONE process: one rt_ctx per device
+ * with the scene replicated, one host thread per device that renders its (row band x sample range) shard with
+ * rt_render_region, then ONE collective: ncclReduce(sum, float32) of the colour image onto the first device (RCCL over
+ * xGMI; librccl.so.1 is loaded on first use, and a group of one device never touches it).  Devices may repeat in the
+ * list (several contexts on one GPU: a rehearsal on a single-GPU box); images that share a GPU are merged with
+ * rt_add_image and RCCL runs among the distinct GPUs only.  The Python driver of the same partition is
+ * raytracing_amd/distributed.py (one process per GPU, torch.distributed). */
+typedef struct rth_multi rth_multi;
+rt_status rth_multi_create(rth_multi** out, const int32_t* devices, int32_t n_devices);
+void rth_multi_destroy(rth_multi* m);
+int32_t rth_multi_size(const rth_multi* m);
+rt_ctx* rth_multi_ctx(rth_multi* m, int32_t i);          /* context i (0 = where the merged frame lands) */
+/* Scene::LoadScene on context 0, then the same six buffers, textures (same handles) and numLights / hasSun on the others. */
+rt_status rth_multi_load_scene(rth_multi* m, const char* models_root, int32_t scene_index);
+rt_status rth_multi_load_models(rth_multi* m, const char* const* gltf_paths, int32_t n_models, const float* lights, int32_t n_lights);
+/* rt_set_int / rt_resize / rth_set_camera on every context. */
+rt_status rth_multi_set_int(rth_multi* m, const char* name, int32_t v);
+rt_status rth_multi_resize(rth_multi* m, uint32_t w, uint32_t h);
+rt_status rth_multi_set_camera(rth_multi* m, const float position[3], const float orientation[3], float screen_w, float screen_h, float fov_deg);
+/* One frame of samplesPerPixel = spp on all contexts: `band_ranks` row bands x (N / band_ranks) sample ranges
+ * (rth_partition), merged onto context 0 (colour; the three AOV images too when merge_aovs != 0).  After a few frames
+ * every context is pinned to context 0's settled kernel choice (rt_stats.kernel_choice), so that shards cost the same. */
+rt_status rth_multi_render_frame(rth_multi* m, uint32_t spp, int32_t band_ranks, int32_t merge_aovs);
+/* 1 when the last rth_multi_render_frame reduced through RCCL, 0 when no collective was needed (one distinct GPU). */
+int32_t rth_multi_used_rccl(const rth_multi* m);
+/* The partition itself (pure index math, the same as raytracing_amd.distributed.partition): shard of `rank` of `world`
+ * -> out = {x, y, w, h, r0, r1} for rt_render_region; w * h == 0 or r0 == r1 means an empty shard. */
+rt_status rth_partition(uint32_t width, uint32_t height, uint32_t spp, int32_t rank, int32_t world, int32_t band_ranks, uint32_t out[6]);
+
 #ifdef __cplusplus
 }
 #endif

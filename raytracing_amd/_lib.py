@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("RT_CORE_LIB") or os.path.join(_HERE, "librt_core.so")
 EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_buffer", "rt_set_int", "rt_set_float",
            "rt_set_vec2", "rt_set_vec3", "rt_set_vec4", "rt_set_mat4", "rt_resize", "rt_create_texture",
            "rt_render_frame", "rt_render_region", "rt_read_image", "rt_write_image", "rt_read_image_rgb", "rt_write_image_rgb", "rt_read_frame_rgba8", "rt_image_device_ptr",
-           "rt_get_stats", "rt_read_primary_hits", "rt_trace_rays", "rt_trace_rays_noalloc"]
+           "rt_add_image", "rt_get_stats", "rt_read_primary_hits", "rt_trace_rays", "rt_trace_rays_noalloc"]
 
 
 class RtConfig(C.Structure):
@@ -70,6 +70,7 @@ def load():
         "rt_write_image_rgb": (i32, [vp, u32, vp]),
         "rt_read_frame_rgba8": (i32, [vp, vp, C.c_uint64]),
         "rt_image_device_ptr": (i32, [vp, u32, C.POINTER(vp)]),
+        "rt_add_image": (i32, [vp, u32, vp]),
         "rt_get_stats": (i32, [vp, C.POINTER(RtStats)]),
         "rt_read_primary_hits": (i32, [vp, vp, vp]),
         "rt_trace_rays": (i32, [vp, vp, vp, u64, vp, vp]),

@@ -25,7 +25,7 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", out or LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread"]
+    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", out or LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-pthread", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -102,6 +102,9 @@ public:
     static std::vector<GPUBoundingBox> BVH();
     static void DeleteAll();
     static std::vector<Model*> instances;
+    // every texture handed to rt_create_texture since the last UnloadScene, in creation order (handle k + 1 = entry k): what
+    // MultiGPU::ReplicateScene re-creates on the other devices so that the material records' handles mean the same there
+    static std::vector<ImageRGBA8> textureLog;
     static double lastFlattenSeconds, lastBuildSeconds, lastUploadSeconds;
 private:
     vec3 pos = vec3(0.f), scale_ = vec3(1.f);
@@ -159,6 +162,36 @@ public:
 private:
     static bool renderering;
     static std::string frameDir;
+};
+
+// Multi-GPU frame driver (no reference counterpart; include/rt_host.h, rth_multi_*).  One context per entry of
+// `devices`, scene replicated, one host thread per context per frame, one RCCL reduce of the colour image.
+struct Shard { uint32_t x = 0, y = 0, w = 0, h = 0, r0 = 0, r1 = 0; bool empty() const { return w == 0 || h == 0 || r1 <= r0; } };
+// `bandRanks` row bands (boundaries on multiples of 8 rows) x world / bandRanks contiguous sample ranges; == distributed.partition
+Shard partition(uint32_t width, uint32_t height, uint32_t spp, int rank, int world, int bandRanks);
+
+class MultiGPU {
+public:
+    explicit MultiGPU(const std::vector<int>& devices);
+    ~MultiGPU();
+    MultiGPU(const MultiGPU&) = delete;
+    MultiGPU& operator=(const MultiGPU&) = delete;
+    size_t size() const { return shaders.size(); }
+    ComputeShader* shader(size_t i) { return shaders[i]; }
+    void ReplicateScene();                                  // after Scene::LoadScene / LoadGPUData on shader(0)
+    void setInt(const std::string& key, int value);
+    void resize(uint32_t w, uint32_t h);
+    void SetFrameUniforms(const Camera* camera, vec2 screenSize);
+    void RenderFrame(uint32_t spp, int bandRanks = 1, bool mergeAovs = false);   // merged frame on shader(0)
+    bool usedRccl() const { return lastUsedRccl; }
+private:
+    struct Impl;
+    Impl* impl = nullptr;
+    std::vector<ComputeShader*> shaders;
+    std::vector<int> devices;
+    uint32_t width = 0, height = 0;
+    int framesRendered = 0;
+    bool kernelsAgreed = false, lastUsedRccl = false;
 };
 
 }  // namespace rt_host

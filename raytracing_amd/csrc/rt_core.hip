@@ -846,6 +846,14 @@ __global__ void k_frame_rgba8(const float4* __restrict__ img, uchar4* __restrict
     out[i] = make_uchar4(cv(v.x), cv(v.y), cv(v.z), cv(v.w));
 }
 
+__global__ void k_add_image(float4* __restrict__ dst, const float4* __restrict__ src, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = dst[i]; const float4 b = src[i];
+    a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
+    dst[i] = a;
+}
+
 bool name_is(const char* a, const char* b) { return std::strcmp(a, b) == 0; }
 
 }  // namespace
@@ -1080,6 +1088,23 @@ rt_status rt_image_device_ptr(rt_ctx* c, uint32_t image, void** p) {
     if (image > 3 || !p) return fail(c, RT_ERR_INVALID, "image must be 0..3");
     if (!c->img[image].p) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
     *p = c->img[image].p;
+    return RT_OK;
+}
+
+rt_status rt_add_image(rt_ctx* c, uint32_t image, const void* src) {
+    if (!c) return RT_ERR_INVALID;
+    if (image > 3 || !src) return fail(c, RT_ERR_INVALID, "image must be 0..3 and src non-NULL");
+    if (!c->img[image].p) return fail(c, RT_ERR_NOT_READY, "rt_resize has not been called");
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) != hipSuccess || at.device != c->device) {
+        (void)hipGetLastError();
+        return fail(c, RT_ERR_INVALID, "src is not device memory of this context's GPU");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = c->width * c->height;
+    k_add_image<<<(n + 255) / 256, 256, 0, c->stream>>>((float4*)c->img[image].p, (const float4*)src, n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

@@ -624,19 +624,7 @@ __device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const Fram
     v3 camPos = ld3(F.camPos);
     const LogPlane LP = log_plane(P, bounce);
     float4* logp = LP.base + logIdx;                 // entry of light l at logp[l * LP.stride]
-    if (ref == -2) {
-        // dead slot (edge tile outside the region)
-    } else if (ref < 0) {
-        // miss: shader.comp:331-336.  A camera ray's miss is not logged: its contribution is the same for every such path
-        // (miss_entry), so k_shade marks the slot's depth word instead and k_resolve adds the constant — 16 bytes less written
-        // and 16 less read for every sample that sees the sky.
-        if (bounce != 0) {
-            const float4 e = miss_entry(F.hasSun, strength);
-            logp[0] = e;
-            for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * LP.stride] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (r == 0 && bounce == 0 && primTri) primTri[(size_t)py * F.width + px] = -1;
-    } else {
+    {      // (only hits get here: misses and dead slots are k_shade's fast path)
         const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
         const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4];
         v3 a = mk(q0.x, q0.y, q0.z), b = mk(q0.w, q1.x, q1.y), c = mk(q1.z, q1.w, q2.x);
@@ -887,7 +875,27 @@ __global__ __launch_bounds__(RT_BLOCK, (TEX ? 3 : 4)) void k_shade(SceneView S, 
         float2 h2 = hq0;
         if (PF) { hq0 = hq1; hq1 = hq2; hq2 = hq3; hq3 = noHit; }
         else if (live) h2 = P.hit[i];
-        if (live) {
+        const int ref = __float_as_int(h2.y);
+        // A path that left the scene (or a dead slot) needs next to nothing — and on the benchmark scenes more than half of
+        // the paths of every bounce are misses.  Bounce 0: the camera ray is not regenerated at all (the depth word alone says
+        // "sky", k_resolve adds the constant; the primary-hit tap was preset to -1).  Later bounces: strength and slot are
+        // read, the ray's origin / direction and the pixel decode (three integer divisions) are not.
+        if (live && ref < 0) {
+            if (bounce == 0) P.depth[slot] = ref == -2 ? 0u : (1u | RT_DEPTH_MISS0);
+            else {
+                const float4 s4 = raySIn[i];
+                slot = __float_as_uint(raysIn[2u * i + 1u].w);
+                const uint32_t logIdx = lateB ? i : slot;
+                if (LATE && (uint32_t)bounce == P.denseBounces) P.lateHead[slot] = i;
+                if (ref != -2) {
+                    const LogPlane LP = log_plane(P, bounce);
+                    float4* logp = LP.base + logIdx;
+                    logp[0] = miss_entry(F.hasSun, mk(s4.x, s4.y, s4.z));      // shader.comp:331-336
+                    for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * LP.stride] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                P.depth[slot] = ref == -2 ? 0u : (uint32_t)bounce + 1u;
+            }
+        } else if (live) {
             v3 rayLoc, rayDir, strength;
             bool refracting = false;
             int px, py, r;
@@ -907,28 +915,25 @@ __global__ __launch_bounds__(RT_BLOCK, (TEX ? 3 : 4)) void k_shade(SceneView S, 
                 r = rBase + (int)sm;
                 slot_to_pixel(F, ps, &px, &py);
             }
-            int ref = __float_as_int(h2.y);
             const uint32_t logIdx = lateB ? i : slot;
             if (LATE && (uint32_t)bounce == P.denseBounces) P.lateHead[slot] = i;
-            const v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122); only used for hits
+            const v3 hitLoc = rayLoc + rayDir * h2.x;      // == the h = o + d * t of the triangle test (shader.comp:122)
             const ShadeResult R = shade_path<TEX, GLASS, MANY, SUN1>(S, F, P, bounce, px, py, r, logIdx, h2, rayLoc, rayDir, strength, refracting, hitLoc,
                                                                      imgAlbedo, imgNormal, imgDepth, primTri, primHit);
             rayLoc = R.o; rayDir = R.d; strength = R.s; refracting = R.refracting; cont = R.cont; wantShadow = R.wantShadow;
             pending += R.pending; skipped += R.skipped;
-            if (ref >= 0) {
-                if (cont || wantShadow) {
-                    const uint32_t st = (uint32_t)item * RT_BLOCK + threadIdx.x;
-                    stageA[st] = make_float4(rayLoc.x, rayLoc.y, rayLoc.z, rayDir.x);
-                    stageB[st] = make_float4(rayDir.y, rayDir.z, strength.x, strength.y);
-                    stageC[st] = strength.z;
-                    if (refracting) refrMask |= 1u << item;
+            if (cont || wantShadow) {
+                const uint32_t st = (uint32_t)item * RT_BLOCK + threadIdx.x;
+                stageA[st] = make_float4(rayLoc.x, rayLoc.y, rayLoc.z, rayDir.x);
+                stageB[st] = make_float4(rayDir.y, rayDir.z, strength.x, strength.y);
+                stageC[st] = strength.z;
+                if (refracting) refrMask |= 1u << item;
 #pragma unroll
-                    for (int k = 0; k < RT_ITEMS; k++) if (item == k) slotK[k] = slot;
-                }
-                if (wantShadow && F.anyPoint) P.shadeLoc[logIdx] = make_float4(hitLoc.x, hitLoc.y, hitLoc.z, 0.f);
+                for (int k = 0; k < RT_ITEMS; k++) if (item == k) slotK[k] = slot;
             }
+            if (wantShadow && F.anyPoint) P.shadeLoc[logIdx] = make_float4(hitLoc.x, hitLoc.y, hitLoc.z, 0.f);
             // bounces shaded by this slot's path: written once, by the bounce at which the path ends
-            if (!cont) P.depth[slot] = ref == -2 ? 0u : (bounce == 0 && ref < 0) ? (1u | RT_DEPTH_MISS0) : (uint32_t)bounce + 1u;
+            if (!cont) P.depth[slot] = (uint32_t)bounce + 1u;
         }
         contMask |= (cont ? 1u : 0u) << item;
         shadowMask |= (wantShadow ? 1u : 0u) << item;

@@ -9,7 +9,9 @@ from . import _lib
 from .core import RtError
 
 HOST_EXPORTS = ["rth_last_error", "rth_load_scene", "rth_load_models", "rth_scene_buffer", "rth_load_timings",
-                "rth_build_bvh", "rth_free", "rth_set_camera", "rth_orbit_camera", "rth_frame_rgba8", "rth_decode_png", "rth_decode_image"]
+                "rth_build_bvh", "rth_free", "rth_set_camera", "rth_orbit_camera", "rth_frame_rgba8", "rth_decode_png", "rth_decode_image",
+                "rth_multi_create", "rth_multi_destroy", "rth_multi_size", "rth_multi_ctx", "rth_multi_load_scene", "rth_multi_load_models",
+                "rth_multi_set_int", "rth_multi_resize", "rth_multi_set_camera", "rth_multi_render_frame", "rth_multi_used_rccl", "rth_partition"]
 
 _bound = False
 
@@ -42,6 +44,30 @@ def _L():
         for f in (lib.rth_decode_png, lib.rth_decode_image):
             f.restype = i32
             f.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
+        lib.rth_multi_create.restype = i32
+        lib.rth_multi_create.argtypes = [C.POINTER(vp), C.POINTER(i32), i32]
+        lib.rth_multi_destroy.restype = None
+        lib.rth_multi_destroy.argtypes = [vp]
+        lib.rth_multi_size.restype = i32
+        lib.rth_multi_size.argtypes = [vp]
+        lib.rth_multi_ctx.restype = vp
+        lib.rth_multi_ctx.argtypes = [vp, i32]
+        lib.rth_multi_load_scene.restype = i32
+        lib.rth_multi_load_scene.argtypes = [vp, C.c_char_p, i32]
+        lib.rth_multi_load_models.restype = i32
+        lib.rth_multi_load_models.argtypes = [vp, C.POINTER(C.c_char_p), i32, C.POINTER(C.c_float), i32]
+        lib.rth_multi_set_int.restype = i32
+        lib.rth_multi_set_int.argtypes = [vp, C.c_char_p, i32]
+        lib.rth_multi_resize.restype = i32
+        lib.rth_multi_resize.argtypes = [vp, u32, u32]
+        lib.rth_multi_set_camera.restype = i32
+        lib.rth_multi_set_camera.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float]
+        lib.rth_multi_render_frame.restype = i32
+        lib.rth_multi_render_frame.argtypes = [vp, u32, i32, i32]
+        lib.rth_multi_used_rccl.restype = i32
+        lib.rth_multi_used_rccl.argtypes = [vp]
+        lib.rth_partition.restype = i32
+        lib.rth_partition.argtypes = [u32, u32, u32, i32, i32, i32, C.POINTER(u32)]
         _bound = True
     return lib
 
@@ -140,3 +166,67 @@ def decode_image(path):
 
 
 decode_png = decode_image
+
+
+def partition(width, height, spp, rank, world, band_ranks=1):
+    """rth_partition: the C++ frame driver's shard of `rank` (the same index math as distributed.partition)."""
+    out = (C.c_uint32 * 6)()
+    _chk(_L().rth_partition(int(width), int(height), int(spp), int(rank), int(world), int(band_ranks), out))
+    return tuple(int(v) for v in out)
+
+
+class MultiGPU:
+    """The C++ multi-GPU frame driver (rt_host::MultiGPU, include/rt_host.h rth_multi_*): one process, one context and one
+    host thread per entry of `devices`, one RCCL reduce of the colour image onto context 0.  Repeated device ordinals put
+    several contexts on one GPU (merged with rt_add_image) — how a single-GPU box rehearses the partition."""
+
+    def __init__(self, devices):
+        self._m = C.c_void_p()
+        arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        _chk(_L().rth_multi_create(C.byref(self._m), arr, len(devices)))
+        self.width = self.height = 0
+
+    def Delete(self):
+        if self._m:
+            _L().rth_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.Delete()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return _L().rth_multi_size(self._m)
+
+    def context(self, i):
+        """A borrowed ComputeShader view of context i (context 0 holds the merged frame)."""
+        from .core import ComputeShader
+        cs = ComputeShader.__new__(ComputeShader)
+        cs._L = _lib.load()
+        cs._h = C.c_void_p(_L().rth_multi_ctx(self._m, int(i)))
+        cs.width, cs.height = self.width, self.height
+        cs.Delete = lambda: None          # owned by the MultiGPU object
+        return cs
+
+    def LoadScene(self, scene_index, models_root):
+        _chk(_L().rth_multi_load_scene(self._m, str(models_root).encode(), int(scene_index)))
+
+    def setInt(self, key, value):
+        _chk(_L().rth_multi_set_int(self._m, key.encode(), int(value)))
+
+    def resize(self, width, height):
+        _chk(_L().rth_multi_resize(self._m, int(width), int(height)))
+        self.width, self.height = int(width), int(height)
+
+    def set_camera(self, position, orientation, width, height, fov=45.0):
+        p = (C.c_float * 3)(*[float(v) for v in position])
+        o = (C.c_float * 3)(*[float(v) for v in orientation])
+        _chk(_L().rth_multi_set_camera(self._m, p, o, float(width), float(height), float(fov)))
+
+    def render_frame(self, spp, band_ranks=1, merge_aovs=False):
+        _chk(_L().rth_multi_render_frame(self._m, int(spp), int(band_ranks), 1 if merge_aovs else 0))
+
+    def used_rccl(self):
+        return bool(_L().rth_multi_used_rccl(self._m))

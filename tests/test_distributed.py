@@ -32,6 +32,23 @@ def test_row_bands_cover_exactly_and_align():
             assert all(a % 8 == 0 for a, b in bs if b > a)
 
 
+def test_cpp_driver_partition_equals_the_python_partition():
+    """The C++ multi-GPU frame driver (rt_host::MultiGPU, rth_partition) and the Python one (distributed.partition) cut a
+    frame into the same shards: same row bands, same sample ranges, for every rank of every split."""
+    from raytracing_amd import scene as S
+    from raytracing_amd.core import RtError
+    for (w, h, spp) in ((1920, 1080, 1024), (3840, 2160, 1024), (96, 64, 6), (7, 5, 3), (512, 512, 64), (800, 600, 100)):
+        for world in (1, 2, 3, 4, 8):
+            for band_ranks in (1, 2, 4, 8):
+                if world % band_ranks:
+                    continue
+                for rank in range(world):
+                    assert S.partition(w, h, spp, rank, world, band_ranks) == tuple(D.partition(w, h, spp, rank, world, band_ranks)), (w, h, spp, rank, world, band_ranks)
+    for bad in ((8, 8, 4, 2, 2, 1), (8, 8, 4, 0, 3, 2), (8, 8, 4, -1, 2, 1), (8, 8, 4, 0, 0, 1)):
+        with pytest.raises(RtError):
+            S.partition(*bad)
+
+
 def test_partition_is_a_partition_of_pixel_samples():
     W, H, spp = 64, 40, 10
     for world, bands in ((2, 1), (2, 2), (4, 2), (8, 2), (8, 8), (8, 1)):

@@ -335,6 +335,32 @@ def test_cpp_example_renders_the_reference_frames(oracle_lib, models_root, tmp_p
     assert (d / "frame_0001.ppm").exists()
 
 
+def test_cpp_example_on_two_contexts_writes_the_same_frames(models_root, tmp_path):
+    """examples/headless_main.cpp with its ninth argument ("0,0": two contexts on the box's one GPU): the C++ multi-GPU frame
+    driver (rt_host::MultiGPU; sample ranges, one merge per frame) writes the frames of the offline render; 8-bit frames of
+    a sample-split render may differ from the single-context ones by a unit in a few pixels (float re-association)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "headless_main")
+    if not os.path.exists(exe):
+        pytest.skip("build/headless_main is not built (cmake -S . -B build -G Ninja && cmake --build build)")
+    W, H, spp, b = 64, 36, 4, 4
+    frames = {}
+    for tag, extra in (("one", []), ("two", ["0,0"])):
+        d0 = tmp_path / tag
+        d0.mkdir()
+        out = subprocess.run([exe, models_root, "4", str(W), str(H), str(spp), str(b), "2", str(d0)] + extra, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        if extra:
+            assert "on 2 contexts" in out.stdout
+        d = d0 / ("Scene-4_spp-%d_bounces-%d" % (spp, b))
+        hdr = b"P6\n%d %d\n255\n" % (W, H)
+        frames[tag] = [np.frombuffer((d / ("frame_%04d.ppm" % f)).read_bytes()[len(hdr):], np.uint8).astype(np.int32) for f in range(2)]
+    for f in range(2):
+        assert np.abs(frames["one"][f] - frames["two"][f]).max() <= 1
+
+
 def test_full_size_frame_is_reproducible_and_stream_independent(oracle_lib, scene4):
     """1920x1080, 48 spp: two renders give the same bits, and so do one stream, three streams with ragged passes and the
     default — the per-pixel sums are replayed in sample order whatever overlaps (the size the multi-stream passes are for)."""
