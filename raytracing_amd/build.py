@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "librt_core.so")
-SOURCES = ["rt_core.hip", "host/rt_host.cpp"]
+SOURCES = ["rt_core.hip", "host/rt_host.cpp", "host/rt_multi.cpp"]
 HEADERS = ["rt_kernels.hip.h", "rt_trace_refill.hip.h", "rt_bvh_sweep.hip.h", "rt_math.h", "rt_types.h", "rt_compact.h", "../../include/rt_core.h",
            "../../include/rt_host.h", "host/rt_host.hpp", "host/bvh_build.h", "host/json.h", "host/png.h", "host/jpeg.h"]
 # -ffp-contract=off: the integrator's float sequence is part of the parity contract.
