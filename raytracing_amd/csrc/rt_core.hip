@@ -399,9 +399,9 @@ rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
     if ((s = ensure(c, ps.shadeLoc, n * 16))) return s;
     if ((s = ensure(c, ps.hit, n * 8))) return s;
     const LogShape g = log_shape(c, nslots, maxBounces);
-    if ((s = ensure(c, ps.contrib, n * 16 * lightSlots * g.dense))) return s;
+    if ((s = ensure(c, ps.contrib, n * sizeof(LogEntry) * lightSlots * g.dense))) return s;
     if (g.lateBounces) {
-        if ((s = ensure(c, ps.late, (size_t)g.lateBounces * lightSlots * g.lateCap * 16))) return s;
+        if ((s = ensure(c, ps.late, (size_t)g.lateBounces * lightSlots * g.lateCap * sizeof(LogEntry)))) return s;
         if ((s = ensure(c, ps.lateNext, (size_t)g.lateBounces * g.lateCap * 4))) return s;
         if ((s = ensure(c, ps.lateHead, n * 4))) return s;
     }
@@ -417,11 +417,11 @@ PathBuffers make_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerS
     rt_ctx::PathSet& ps = c->set[which];
     for (int k = 0; k < 2; k++) { P.ray[k] = (float4*)ps.ray[k].p; P.rayS[k] = (float4*)ps.rayS[k].p; }
     P.hit = (float2*)ps.hit.p; P.shadowRec = (float4*)ps.shadowRec.p; P.shadeLoc = (float4*)ps.shadeLoc.p;
-    P.contrib = (float4*)ps.contrib.p; P.depth = (uint32_t*)ps.depth.p; P.accum = (float4*)c->accum.p;
+    P.contrib = (LogEntry*)ps.contrib.p; P.depth = (uint32_t*)ps.depth.p; P.accum = (float4*)c->accum.p;
     P.counters = (uint32_t*)ps.counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots; P.grpShift = 0;
     const LogShape g = log_shape(c, nslots, maxBounces);
-    P.late = (float4*)ps.late.p; P.lateNext = (uint32_t*)ps.lateNext.p; P.lateHead = (uint32_t*)ps.lateHead.p;
+    P.late = (LogEntry*)ps.late.p; P.lateNext = (uint32_t*)ps.lateNext.p; P.lateHead = (uint32_t*)ps.lateHead.p;
     P.denseBounces = g.lateBounces ? g.dense : 0xffffffffu; P.lateCap = g.lateCap;
     P.overflow = (uint2*)ps.overflow.p; P.overflowStride = stack_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
@@ -479,8 +479,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     {
         const LogShape g = log_shape(c, 1u << 20, maxB);      // (shape only: the dense / late split does not depend on the slot count)
         const uint64_t L = (uint64_t)std::max(1, F.numLights);
-        const uint64_t lateBytes = g.lateBounces ? 4 + ((uint64_t)g.lateBounces * (16 * L + 4) * (uint64_t)std::min(std::max(c->lateLogPercent, 1), 100) + 99) / 100 : 0;
-        const uint64_t bytesPerSlot = 2 * 32 + 2 * 16 + 8 + 16 + 16 + 4 + 16ull * L * g.dense + lateBytes;
+        const uint64_t lateBytes = g.lateBounces ? 4 + ((uint64_t)g.lateBounces * (sizeof(LogEntry) * L + 4) * (uint64_t)std::min(std::max(c->lateLogPercent, 1), 100) + 99) / 100 : 0;
+        const uint64_t bytesPerSlot = 2 * 32 + 2 * 16 + 8 + 16 + 16 + 4 + (uint64_t)sizeof(LogEntry) * L * g.dense + lateBytes;
         const uint64_t wantSets = (uint64_t)std::min<int>(std::max(1, (int)c->passStreams), rt_ctx::kMaxSets);
         uint64_t slotBudget = std::min<uint64_t>(1ull << 30, (c->deviceBytes / 100 * (uint64_t)std::min(std::max(c->pathMemPercent, 1), 90)) / (wantSets * bytesPerSlot));
         if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);

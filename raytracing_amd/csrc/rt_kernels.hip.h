@@ -22,6 +22,15 @@ namespace rt {
 
 #define RT_BLOCK 256
 
+// An entry of the contribution log (PathBuffers::contrib): three floats, 12 bytes.
+#ifdef RT_EXP_LOG16
+typedef float4 LogEntry;
+__device__ __forceinline__ LogEntry log_entry(float x, float y, float z) { return make_float4(x, y, z, 0.f); }
+#else
+typedef float3 LogEntry;
+__device__ __forceinline__ LogEntry log_entry(float x, float y, float z) { return make_float3(x, y, z); }
+#endif
+
 struct PathBuffers {
     // Per-path state lives at the path's POSITION IN ITS BOUNCE'S QUEUE, not at its slot: a bounce's kernels then read
     // and write it with dense, coalesced accesses instead of gathers through a queue of slot ids (the scattered
@@ -33,12 +42,17 @@ struct PathBuffers {
     float4* shadowRec;   // shadow-queue entry j: (origin.xyz, slot bits)
     float4* shadeLoc;    // [slot] hitLoc of the bounce being shaded, written only when a point light needs it (k_shadow)
     // Indexed by slot (one per sample of the pass and pixel: slot_split), because k_resolve replays them per pixel:
-    float4* contrib;     // contribution log [maxBounces][lightSlots][nslots]: rgb, w = 0 none / 1 awaiting shadow ray / 2 add
+    // Contribution log [maxBounces][lightSlots][nslots], 12 bytes per entry: what `color +=` adds at that bounce for that
+    // light, or +0 where nothing is added (N.L <= 0, a contribution of exactly zero, an occluded light: k_shade writes the
+    // contribution, the shadow kernels overwrite it with zeros when the light is occluded).  The replay adds every entry of a
+    // path's bounces: x + (+0) == x bit for bit for every x the sum can hold (it starts at +0 and a sum is -0 only if both
+    // operands are, so it never is -0; NaN stays NaN), so an entry needs no state word.
+    LogEntry* contrib;
     uint32_t* depth;     // [nslots] bounces shaded by the slot's path (log entries [0, depth) are valid)
     // Deep-bounce renders keep only the first `denseBounces` planes of the log per slot; later bounces, which few paths
     // reach, log at their path's POSITION IN THAT BOUNCE'S QUEUE (lateCap entries per bounce) and a slot finds its entries
     // through lateHead (its position at bounce denseBounces) and lateNext (from a position to the next bounce's).
-    float4* late;        // [maxBounces - denseBounces][lightSlots][lateCap]
+    LogEntry* late;        // [maxBounces - denseBounces][lightSlots][lateCap]
     uint32_t* lateNext;  // [maxBounces - denseBounces][lateCap]
     uint32_t* lateHead;  // [nslots]
     uint32_t denseBounces, lateCap;      // denseBounces >= maxBounces: the whole log is dense
@@ -57,7 +71,7 @@ __device__ __forceinline__ void unpack_ray(float4 a, float4 b, v3& o, v3& d, uin
 
 // The log entries of one bounce: entry of light l and log index x at base[l * stride + x], where x is the path's slot
 // for a bounce of the dense part and its position in the bounce's queue for a later one.
-struct LogPlane { float4* base; size_t stride; };
+struct LogPlane { LogEntry* base; size_t stride; };
 __device__ __forceinline__ LogPlane log_plane(const PathBuffers& P, int bounce) {
     LogPlane L;
     if ((uint32_t)bounce < P.denseBounces) { L.base = P.contrib + (size_t)bounce * P.lightSlots * P.nslots; L.stride = P.nslots; }
@@ -607,10 +621,10 @@ __device__ __forceinline__ v3 sample_ggx(v3 N, float rand1, float rand2, float a
 // next ray and strength, cont (the path goes on to bounce + 1), wantShadow (a log entry awaits its shadow ray, whose origin
 // is the new rayLoc).  hitLoc = rayLoc + rayDir * t, formed by the caller.
 // shader.comp:331-336: what a path that leaves the scene adds, as a log entry (w = 2: add).
-__device__ __forceinline__ float4 miss_entry(int hasSun, v3 strength) {
+__device__ __forceinline__ LogEntry miss_entry(int hasSun, v3 strength) {
     v3 ambient = hasSun ? mk(0.4431372549f, 0.73725490196f, 1.f) : mk(0.f, 0.f, 0.f);
     v3 cc = ambient * strength;
-    return make_float4(cc.x, cc.y, cc.z, 2.f);
+    return log_entry(cc.x, cc.y, cc.z);
 }
 #define RT_DEPTH_MISS0 0x80000000u      // depth word of a slot whose camera ray missed: 1 | this, and no log entry (k_resolve adds miss_entry)
 struct ShadeResult { v3 o, d, s; bool refracting, cont, wantShadow; uint32_t pending, skipped; };
@@ -623,7 +637,7 @@ __device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const Fram
     int ref = __float_as_int(h2.y);
     v3 camPos = ld3(F.camPos);
     const LogPlane LP = log_plane(P, bounce);
-    float4* logp = LP.base + logIdx;                 // entry of light l at logp[l * LP.stride]
+    LogEntry* logp = LP.base + logIdx;                 // entry of light l at logp[l * LP.stride]
     {      // (only hits get here: misses and dead slots are k_shade's fast path)
         const float4* sp = reinterpret_cast<const float4*>(S.shade + ref);
         const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], q4 = sp[4];
@@ -746,7 +760,7 @@ __device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const Fram
         }
 
         // light loop, shader.comp:453-522 minus the shadow lineCast (k_shadow)
-        if (!SUN1 && F.numLights == 0) logp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!SUN1 && F.numLights == 0) logp[0] = log_entry(0.f, 0.f, 0.f);
         const int nLightsHere = SUN1 ? 1 : F.numLights;
         for (int l = 0; l < nLightsHere; l++) {
             const RefLight Lg = MANY ? light_at(S, F, l) : F.lights[l];
@@ -766,7 +780,7 @@ __device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const Fram
                 cast = true;
             }
             float NdotL = gmax(dot3(normal, dirToLight), 0.0f);
-            float4 pendOut = make_float4(0.f, 0.f, 0.f, 0.f);
+            LogEntry pendOut = log_entry(0.f, 0.f, 0.f);
             if (!(NdotL <= 0.0f)) {
                 v3 Hh = normalize3(viewDir + dirToLight);
                 float NdotH = gmax(dot3(normal, Hh), 0.0f);
@@ -790,11 +804,11 @@ __device__ __forceinline__ ShadeResult shade_path(const SceneView& S, const Fram
                 const bool nothing = cast && contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f;
                 if (nothing) skipped++;
                 else {
-                    pendOut = make_float4(contrib.x, contrib.y, contrib.z, cast ? 1.f : 2.f);
+                    pendOut = log_entry(contrib.x, contrib.y, contrib.z);
                     if (cast) { wantShadow = true; pending++; }
                 }
-                // cast == false: a light type the shader does not know gets no shadow test and its
-                // contribution (only reachable with a NaN normal) is added directly: w = 2
+                // cast == false: a light type the shader does not know gets no shadow test (the shadow kernels skip such
+                // lights) and its contribution (only reachable with a NaN normal) is added as it stands
             } else if (cast) skipped++;
             logp[(size_t)l * LP.stride] = pendOut;
         }
@@ -889,9 +903,9 @@ __global__ __launch_bounds__(RT_BLOCK, (TEX ? 3 : 4)) void k_shade(SceneView S, 
                 if (LATE && (uint32_t)bounce == P.denseBounces) P.lateHead[slot] = i;
                 if (ref != -2) {
                     const LogPlane LP = log_plane(P, bounce);
-                    float4* logp = LP.base + logIdx;
+                    LogEntry* logp = LP.base + logIdx;
                     logp[0] = miss_entry(F.hasSun, mk(s4.x, s4.y, s4.z));      // shader.comp:331-336
-                    for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * LP.stride] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (uint32_t l = 1; l < P.lightSlots; l++) logp[(size_t)l * LP.stride] = log_entry(0.f, 0.f, 0.f);
                 }
                 P.depth[slot] = ref == -2 ? 0u : (uint32_t)bounce + 1u;
             }
@@ -988,7 +1002,7 @@ __device__ __forceinline__ void shadow_sun_batch(const SceneView& S, const Frame
     const v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float big = 3.0e38f;
     const bool dPlain = fabsf(d.x) < big && fabsf(d.y) < big && fabsf(d.z) < big && d.x != 0.f && d.y != 0.f && d.z != 0.f;
-    float4* const logBase = log_plane(P, bounce).base;
+    LogEntry* const logBase = log_plane(P, bounce).base;
     for (uint32_t i = bid * RT_BLOCK + threadIdx.x; i < n; i += nblk * RT_BLOCK) {
         const float4 o4 = P.shadowRec[i];
         const uint32_t slot = __float_as_uint(o4.w);
@@ -1038,7 +1052,7 @@ __device__ __forceinline__ void shadow_sun_batch(const SceneView& S, const Frame
                 }
             }
         }
-        logBase[slot].w = occ ? 0.f : 2.f;
+        if (occ) logBase[slot] = log_entry(0.f, 0.f, 0.f);      // an occluded light adds nothing (PathBuffers::contrib)
     }
 }
 
@@ -1061,13 +1075,20 @@ __device__ __forceinline__ void shadow_batch(const SceneView& S, const FramePara
         v3 o = mk(o4.x, o4.y, o4.z), hitLoc = mk(0.f, 0.f, 0.f);
         if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; hitLoc = mk(h4.x, h4.y, h4.z); }
         const LogPlane LP = log_plane(P, bounce);
-        float4* logp = LP.base + slot;
+        LogEntry* logp = LP.base + slot;
         for (int l = 0; l < F.numLights; l++) {
-            float* wp = &logp[(size_t)l * LP.stride].w;
-            if (F.numLights > 1 && *wp != 1.f) continue;     // (one light: a queued slot always awaits its shadow ray)
+            LogEntry* ep = &logp[(size_t)l * LP.stride];
             const RefLight Lg = light_at(S, F, l);
             float4 L0 = make_float4(Lg.loc.x, Lg.loc.y, Lg.loc.z, Lg.strength), L1 = make_float4(Lg.dir.x, Lg.dir.y, Lg.dir.z, 0.f);
             uint32_t ltype = Lg.lightType;
+            // Which entries await a shadow ray: those of a light type the shader casts for (shader.comp:462,476) whose
+            // contribution is not exactly zero (k_shade logs +0 for N.L <= 0 and for contributions of +-0, and does not cast
+            // for them).  One light: a queued slot always awaits its shadow ray, nothing to read.
+            if (F.numLights > 1) {
+                if (ltype > 1u) continue;
+                const LogEntry e = *ep;
+                if (e.x == 0.f && e.y == 0.f && e.z == 0.f) continue;
+            }
             v3 dirToLight; float distToLight = 0.f;
             if (ltype == 0u) {
                 v3 toL = mk(L0.x, L0.y, L0.z) - hitLoc;
@@ -1086,7 +1107,7 @@ __device__ __forceinline__ void shadow_batch(const SceneView& S, const FramePara
                 occ = plain ? occluded_fast<COUNT, true>(S, o, dirToLight, (int)ltype, hitLoc, distToLight, stk, nNodes, nTris)
                             : occluded_fast<COUNT, false>(S, o, dirToLight, (int)ltype, hitLoc, distToLight, stk, nNodes, nTris);
             }
-            *wp = occ ? 0.f : 2.f;
+            if (occ) *ep = log_entry(0.f, 0.f, 0.f);
         }
     }
     if (COUNT) {
@@ -1118,14 +1139,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView S, FrameParams F,
 #ifndef RT_RESOLVE_AHEAD
 #define RT_RESOLVE_AHEAD 4
 #endif
-__device__ __forceinline__ void resolve_add(float4& acc, float4 e) {
-    if (e.w == 2.f) { acc.x = acc.x + e.x; acc.y = acc.y + e.y; acc.z = acc.z + e.z; }
+__device__ __forceinline__ void resolve_add(float4& acc, LogEntry e) {
+    acc.x = acc.x + e.x; acc.y = acc.y + e.y; acc.z = acc.z + e.z;
 }
 // bounces [b0, d) of the path in `slot`, in order
 __device__ __forceinline__ void resolve_from(const PathBuffers& P, float4& acc, uint32_t slot, uint32_t b0, uint32_t d) {
     const uint32_t dDense = d < P.denseBounces ? d : P.denseBounces;
     for (uint32_t b = b0; b < dDense; b++) {
-        const float4* logp = P.contrib + (size_t)b * P.lightSlots * P.nslots + slot;
+        const LogEntry* logp = P.contrib + (size_t)b * P.lightSlots * P.nslots + slot;
         for (uint32_t l = 0; l < P.lightSlots; l++) resolve_add(acc, logp[(size_t)l * P.nslots]);
     }
     if (d > dDense) {
@@ -1136,7 +1157,7 @@ __device__ __forceinline__ void resolve_from(const PathBuffers& P, float4& acc, 
             const size_t plane = (size_t)(b - P.denseBounces);
             const uint32_t nxt = P.lateNext[plane * P.lateCap + i];
             if (b >= b0) {
-                const float4* logp = P.late + plane * P.lightSlots * P.lateCap + i;
+                const LogEntry* logp = P.late + plane * P.lightSlots * P.lateCap + i;
                 for (uint32_t l = 0; l < P.lightSlots; l++) resolve_add(acc, logp[(size_t)l * P.lateCap]);
             }
             i = nxt;
@@ -1146,7 +1167,7 @@ __device__ __forceinline__ void resolve_from(const PathBuffers& P, float4& acc, 
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathBuffers P, int samplesInPass, int maxBounces, int hasSun, float initialStrength) {
     uint32_t ps = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (ps >= P.slotsPerSample) return;
-    const float4 miss0 = miss_entry(hasSun, mk(initialStrength, initialStrength, initialStrength));      // a camera ray's miss (k_shade, bounce 0)
+    const LogEntry miss0 = miss_entry(hasSun, mk(initialStrength, initialStrength, initialStrength));      // a camera ray's miss (k_shade, bounce 0)
     float4 acc = P.accum[ps];
     const uint32_t S = (uint32_t)samplesInPass;
     // (two bounces ahead only where both are planes of the dense part)
@@ -1159,17 +1180,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathBuffers P, int samples
             d[k] = sm0 + (uint32_t)k < S ? P.depth[slot[k]] : 0u;
         }
         if (ahead) {
-            float4 e0[RT_RESOLVE_AHEAD], e1[RT_RESOLVE_AHEAD];
+            LogEntry e0[RT_RESOLVE_AHEAD], e1[RT_RESOLVE_AHEAD];
 #pragma unroll
             for (int k = 0; k < RT_RESOLVE_AHEAD; k++) {
-                e0[k] = make_float4(0.f, 0.f, 0.f, 0.f); e1[k] = e0[k];
+                e0[k] = log_entry(0.f, 0.f, 0.f); e1[k] = e0[k];
                 if (d[k] & RT_DEPTH_MISS0) { e0[k] = miss0; d[k] = 1u; }
                 else if (d[k] > 0u) e0[k] = P.contrib[slot[k]];
                 if (d[k] > 1u) e1[k] = P.contrib[(size_t)P.nslots + slot[k]];
             }
 #pragma unroll
             for (int k = 0; k < RT_RESOLVE_AHEAD; k++) {
-                resolve_add(acc, e0[k]);          // (w = 0 where there is no such bounce: nothing added)
+                resolve_add(acc, e0[k]);          // (+0 where there is no such bounce: nothing changes)
                 resolve_add(acc, e1[k]);
                 if (d[k] > 2u) resolve_from(P, acc, slot[k], 2u, d[k]);
             }

@@ -407,7 +407,12 @@ __device__ __forceinline__ void shadow_refill(const SceneView& S, const FramePar
     uint32_t nNodes = 0, nTris = 0;
 
     bool active = false, occ = false;
-    float* wptr = nullptr;
+    // the ray's log entry, zeroed if the light turns out to be occluded (PathBuffers::contrib).  SUN1: the entry's index in
+    // the bounce's plane instead of its address (one register less: the fused kernel of the two-level walk sits at the
+    // 80-register step between 6 and 5 waves per SIMD)
+    LogEntry* wptr = nullptr;
+    uint32_t wslot = 0;
+    LogEntry* const sunPlane = SUN1 ? log_plane(P, bounce).base : nullptr;
     v3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f), shadeLoc = mk(0.f, 0.f, 0.f);
     v3 rinv = mk(1.f, 1.f, 1.f);
     float distToLight = 0.f, lim = INF;
@@ -436,30 +441,26 @@ __device__ __forceinline__ void shadow_refill(const SceneView& S, const FramePar
                     const float4 rec = P.shadowRec[q];
                     const uint32_t slot = __float_as_uint(rec.w);      // the path's log index (log_plane)
                     const LogPlane LP = log_plane(P, bounce);
-                    float* wp_ = &LP.base[(size_t)l * LP.stride + slot].w;
-                    // one light: every queued entry awaits its shadow ray (k_shade queued it for that reason), so the
-                    // scattered read of the flag is not needed
+                    LogEntry* wp_ = SUN1 ? nullptr : &LP.base[(size_t)l * LP.stride + slot];
+                    // one light: every queued entry awaits its shadow ray (k_shade queued it for that reason), so nothing
+                    // of the entry is read here; it is only overwritten (with zeros) if the light turns out to be occluded
                     if (SUN1) {
                         o = mk(rec.x, rec.y, rec.z);
-                        wptr = wp_;
+                        wslot = slot;
                         if (!(sunPlain && ray_is_plain(o, mk(1.f, 1.f, 1.f)))) {
                             bool oc = occluded_fast<COUNT, false>(S, o, d, 1, mk(0.f, 0.f, 0.f), 0.f, stk, nNodes, nTris);
-                            *wptr = oc ? 0.f : 2.f;
+                            if (oc) sunPlane[wslot] = log_entry(0.f, 0.f, 0.f);
                         } else {
                             float te;
                             if (COUNT) nNodes++;
-                            if (!slab<true>(o, sunInv, S.rootLo, S.rootHi, &te)) {
-                                *wptr = 2.f;
-                            } else {
+                            if (slab<true>(o, sunInv, S.rootLo, S.rootHi, &te)) {      // (a ray that misses the scene's box is not occluded: the entry stands)
                                 rinv = sunInv;
                                 occ = false; sp = 0; cur = S.rootChild; pend = RT_DONE;
                                 if (cur < 0) { pend = cur; cur = RT_DONE; }
                                 active = true;
                             }
                         }
-                    } else if (L == 1u || *wp_ == 1.f) {
-                        o = mk(rec.x, rec.y, rec.z); shadeLoc = mk(0.f, 0.f, 0.f);
-                        if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; shadeLoc = mk(h4.x, h4.y, h4.z); }
+                    } else {
                         float4 L0, L1;
                         if (L == 1u) {         // kernarg, uniform: scalar loads
                             const RefLight& Lg = F.lights[0];
@@ -469,29 +470,38 @@ __device__ __forceinline__ void shadow_refill(const SceneView& S, const FramePar
                             const float4* lp = reinterpret_cast<const float4*>(S.lights + l);
                             L0 = lp[0]; L1 = lp[1];
                         }
-                        kind = (int)__float_as_uint(L1.w);
-                        distToLight = 0.f;
-                        if (kind == 0) {
-                            v3 toL = mk(L0.x, L0.y, L0.z) - shadeLoc;
-                            d = normalize3(toL);
-                            distToLight = length3(toL);
-                        } else d = -mk(L1.x, L1.y, L1.z);
-                        wptr = wp_;
-                        if (!ray_is_plain(o, d)) {
-                            bool oc = occluded_fast<COUNT, false>(S, o, d, kind, shadeLoc, distToLight, stk, nNodes, nTris);
-                            *wptr = oc ? 0.f : 2.f;
-                        } else {
-                            v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                            float te;
-                            if (COUNT) nNodes++;
-                            if (!slab<true>(o, inv, S.rootLo, S.rootHi, &te)) {
-                                *wptr = 2.f;
+                        // several lights: the entries that await a shadow ray are those of a light type the shader casts
+                        // for whose contribution is not exactly zero (shadow_batch)
+                        bool awaits = true;
+                        if (L != 1u) {
+                            const LogEntry e = *wp_;
+                            awaits = __float_as_uint(L1.w) <= 1u && !(e.x == 0.f && e.y == 0.f && e.z == 0.f);
+                        }
+                        if (awaits) {
+                            o = mk(rec.x, rec.y, rec.z); shadeLoc = mk(0.f, 0.f, 0.f);
+                            if (F.anyPoint) { float4 h4 = P.shadeLoc[slot]; shadeLoc = mk(h4.x, h4.y, h4.z); }
+                            kind = (int)__float_as_uint(L1.w);
+                            distToLight = 0.f;
+                            if (kind == 0) {
+                                v3 toL = mk(L0.x, L0.y, L0.z) - shadeLoc;
+                                d = normalize3(toL);
+                                distToLight = length3(toL);
+                            } else d = -mk(L1.x, L1.y, L1.z);
+                            wptr = wp_;
+                            if (!ray_is_plain(o, d)) {
+                                bool oc = occluded_fast<COUNT, false>(S, o, d, kind, shadeLoc, distToLight, stk, nNodes, nTris);
+                                if (oc) *wptr = log_entry(0.f, 0.f, 0.f);
                             } else {
-                                rinv = inv;
-                                lim = (kind == 0) ? (distToLight + distToLight * 1e-3f + S.cullAbs * 4.0f) : INF;
-                                occ = false; sp = 0; cur = S.rootChild; pend = RT_DONE;
-                                if (cur < 0) { pend = cur; cur = RT_DONE; }
-                                active = true;
+                                v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                                float te;
+                                if (COUNT) nNodes++;
+                                if (slab<true>(o, inv, S.rootLo, S.rootHi, &te)) {
+                                    rinv = inv;
+                                    lim = (kind == 0) ? (distToLight + distToLight * 1e-3f + S.cullAbs * 4.0f) : INF;
+                                    occ = false; sp = 0; cur = S.rootChild; pend = RT_DONE;
+                                    if (cur < 0) { pend = cur; cur = RT_DONE; }
+                                    active = true;
+                                }
                             }
                         }
                     }
@@ -561,7 +571,7 @@ __device__ __forceinline__ void shadow_refill(const SceneView& S, const FramePar
                 else if (cur < 0 && cur != RT_DONE) { pend = cur; popS(); }
             }
             if (active && cur == RT_DONE && pend == RT_DONE) {
-                *wptr = occ ? 0.f : 2.f;
+                if (occ) { if (SUN1) sunPlane[wslot] = log_entry(0.f, 0.f, 0.f); else *wptr = log_entry(0.f, 0.f, 0.f); }
                 active = false;
             }
             const unsigned long long am = __ballot(active);
