@@ -8,8 +8,9 @@ A step = one complete frame (all samples, all bounces) of the hot path with the 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's samples are split into N
 contiguous ranges (scene + BVH replicated), every rank traces its range over the whole image and the HDR
 colour buffers are summed onto rank 0 with one RCCL reduce — the only collective (strong scaling).
-Before the warm-up every rank renders --prepare-frames frames (default 5): the first allocates the path buffers, the
-next four are the library's per-scene trial of its traversal kernels (scene preparation, reported in scene_load_s).
+Before the warm-up every rank renders --prepare-frames frames (default 8): the first allocates the path buffers, the
+next four are the library's per-scene trial of its traversal kernels, up to three more its trial of the pass shape
+(scene preparation, reported in scene_load_s).
 Rank 0 prints ONE JSON line.  One ray = one lineCast of shader.comp (camera/bounce segment or shadow ray)
 actually traced by the kernels (device counters).
 """
@@ -56,7 +57,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     # scene preparation, before the warm-up: frame 1 allocates the path buffers, frames 2 to 5 are the library's trial of
     # its traversal kernels for this scene (rt_core.h, refill); reported as scene_load_s.kernel_trial_s
-    ap.add_argument("--prepare-frames", type=int, default=5)
+    # (+ up to three for the pass shape: one that re-allocates the path buffers, one that is timed, and — if the default shape
+    # is kept — one that allocates them back)
+    ap.add_argument("--prepare-frames", type=int, default=8)
     # workload = a BASELINE.json config; c2 is the headline (the default), the others are reported for context
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     # development overrides (a run with any of these set is labelled in config and is not the headline)
@@ -410,9 +413,11 @@ def main():
                        "parallelism": "sample-range x%d, %s reduce of the colour buffer" % (world, "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else "single GPU",
                        "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None,
                        "traversal": "culled/ordered (traversalMode 0)",
-                       "traversal_kernels": KERNEL_CHOICE.get(last_stats.get("kernel_choice"), "?") +
+                       "traversal_kernels": KERNEL_CHOICE.get(last_stats.get("kernel_choice") if last_stats.get("kernel_choice", 0) < 0 else last_stats.get("kernel_choice") & 3, "?") +
                                             (" on two-level nodes (128-byte records, %d steps deep)" % last_stats.get("wide_depth", 0) if last_stats.get("wide_nodes") else "") +
-                                            ("" if last_stats.get("kernel_choice_settled") else " [trial not finished]")},
+                                            ("" if last_stats.get("kernel_choice_settled") else " [trial not finished]"),
+                       "pass_shape": ("half the pass streams, twice the samples per pass (measured faster for this scene)"
+                                      if last_stats.get("kernel_choice", 0) >= 0 and (last_stats.get("kernel_choice", 0) & 4) else "default pass streams and samples per pass")},
             "rays": {"total": rays, "primary": agg["rays_primary"], "bounce": agg["rays_bounce"], "shadow": agg["rays_shadow"],
                      "shadow_skipped": agg["rays_shadow_skipped"], "note": "rank-0 split; total is all ranks" if world > 1 else "per %d steps" % args.steps},
             "scene_load_s": load_t,

@@ -78,13 +78,16 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * 2^sampleGroup samples of 64 >> sampleGroup neighbouring pixels; results do not depend on it), logDenseBounces (0 automatic: 4 when maxBounces > 8, else all) and lateLogPercent (default 25): the
  * contribution log keeps an entry per slot for that many bounces and, for the later ones, per queue position, as many as that
  * share of the slots (a frame that needs more is rendered again with a dense log; results do not depend on either),
- * pathMemPercent (default 50: share of device memory the path state may take; caps the
+ * pathMemPercent (default 75: share of device memory the path state may take; caps the
  * samples per pass), blocksPerCU (persistent grid size), passStreams (1..8, default 4: consecutive
  * passes of samplesPerPass samples run on that many HIP streams with their own path buffers and overlap; the per-pixel
- * sum is still replayed in sample order, so results do not depend on it), refill (-1 automatic / 0 / 1: persistent
+ * sum is still replayed in sample order, so results do not depend on it; unless the caller sets passStreams or
+ * samplesPerPass, the frames after the kernel trial also measure half the streams with twice the samples per pass and
+ * keep that pass shape for the scene if it is 2 % faster), refill (-1 automatic / 0 / 1: persistent
  * traversal waves that hand finished lanes new rays; automatic = the first four sizeable frames after a scene upload
  * are rendered with the four combinations (refill or not, for closest-hit and for shadow rays) and the fastest is kept;
- * until then closest-hit rays of bounces >= 1 use them, and shadow rays do where the BVH is far larger than the L2s), kernelChoice (-1 / 0..3: that combination whatever
+ * until then closest-hit rays of bounces >= 1 use them, and shadow rays do where the BVH is far larger than the L2s), kernelChoice (-1 / 0..7: bits 0 and 1 that combination, bit 2 the pass
+ * shape (1: half the streams, twice the samples per pass), whatever
  * was measured, reported back in rt_stats.kernel_choice; a multi-GPU job gives every rank rank 0's), fusePairs (1 / 0: the
  * shadow rays of a bounce and the closest-hit rays of the next are traced by one launch), wideNodes (-1 / 0 / 1: the refill
  * kernels walk two-level nodes derived from the same tree, by default for BVHs far larger than the L2s; same images), refillIdle, refillNodeMin,
@@ -165,8 +168,9 @@ typedef struct rt_stats {
     double   ms_extend_primary;      /* the part of ms_extend / launches_extend spent on camera rays (bounce 0)       */
     uint64_t launches_extend_primary;
     int32_t  kernel_choice;    /* traversal kernels this call ran: bit 0 = refill kernel for closest-hit rays of bounces >= 1,
-                                  bit 1 = for shadow rays; -2 = reference-order walk (traversalMode 1 or forced) */
-    int32_t  kernel_choice_settled;  /* 1: fixed by a knob or by the finished per-scene trial; 0: a trial frame or the default */
+                                  bit 1 = for shadow rays, bit 2 = the pass shape the next call will use (half the streams, twice the
+                                  samples per pass); -2 = reference-order walk (traversalMode 1 or forced) */
+    int32_t  kernel_choice_settled;  /* 1: fixed by a knob or by the finished per-scene trials (kernels, then pass shape); 0: a trial frame or the default */
     uint64_t launches_pair;    /* launches that traced the shadow rays of a bounce and the closest-hit rays of the next together
                                   (k_trace_pair, knob fusePairs); they are counted and timed under launches_extend / ms_extend */
     int32_t  wide_nodes;       /* 1: the refill kernels of this call walked two-level nodes (knob wideNodes and a tree that qualifies) */

@@ -91,7 +91,7 @@ struct rt_ctx {
     float camPos[3] = {0, 0, 0}, camForward[3] = {0, 0, -1}, camRight[3] = {1, 0, 0}, camUp[3] = {0, 1, 0};
     float aspect = 1.f, fov = 45.f;
     float offset[2] = {0, 0};
-    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64, sampleGroup = -1, pathMemPercent = 50, logDenseBounces = 0, lateLogPercent = 25;
+    int32_t traversalMode = 0, timeKernels = 0, countVisits = 0, samplesPerPass = 64, blocksPerCU = 64, sampleGroup = -1, pathMemPercent = 75, logDenseBounces = 0, lateLogPercent = 25;
     uint32_t lateLogFallbacks = 0;
     bool lateLogOff = false;      // a frame overflowed the compact part of the log: this context keeps a dense log from then on
 
@@ -131,6 +131,15 @@ struct rt_ctx {
     double tuneRate[4] = {0.0, 0.0, 0.0, 0.0};
     uint64_t sceneKey = 0;      // content key of the scene on the device (scene_key): the trial's result is remembered under it
     int32_t tuneCache = 1;      // 0: always run the trial (knob)
+    // Pass shape.  Default: `passStreams` (4) streams of up to `samplesPerPass` (64) samples.  Scenes whose launches end in
+    // long latency-bound tails (scene 7's glass: a ray inside it walks ~750 dependent steps) render faster with half the
+    // streams and twice the samples per pass (C5 -4 %, C3 -4 %), others slower (C2 +3 %, C4 +5 %): measured per scene, after
+    // the kernel trial, on one more sizeable frame (plus the frame that re-allocates the path buffers, which is no sample).
+    // Not tried when the caller set passStreams or samplesPerPass.
+    bool streamsUser = false, sppUser = false;
+    int shapeState = 0;         // 0: not measured yet, 1: measuring, 2: decided (shapeChoice)
+    int shapeChoice = 0;        // 1: half the streams, twice the samples per pass
+    double tuneRateBase = 0.0;  // rays per ms of the kept kernel combination with the default shape
     int tuneChoice = 0;         // bit 0: refill kernel for closest-hit rays, bit 1: for shadow rays
     int32_t kernelChoice = -1;  // >= 0: this combination (bit 0 / bit 1 as tuneChoice) whatever was measured: every rank of a
                                 // multi-GPU job is given rank 0's choice, so that shards cost the same everywhere
@@ -190,6 +199,7 @@ const size_t kRecordSize[6] = {80, 64, 80, 48, 128, 48};
 // two-level nodes are their defaults
 constexpr size_t kBigBvhBytes = (size_t)64 << 20;
 size_t bvh_bytes(const rt_ctx* c) { return c->cs.nodes.size() * sizeof(CNode) + (size_t)c->cs.nTris * sizeof(CTri); }
+bool shape_user(const rt_ctx* c) { return c->streamsUser || c->sppUser; }      // the caller chose the pass shape: no trial of it
 bool want_wide(const rt_ctx* c) { return c->wideNodes > 0 || (c->wideNodes < 0 && bvh_bytes(c) > kBigBvhBytes); }
 
 // FNV-1a over the sizes of slots 0..4 and up to 256 evenly spaced 64-byte samples of the node and triangle buffers
@@ -235,13 +245,13 @@ rt_status sync_scene(rt_ctx* c) {
         c->uvReady = false;
         if (dbgT) std::fprintf(stderr, "[rt] scene sync: compact layout derived in %.3f s, uploaded in %.3f s\n", tSec(tc0, tc1), tSec(tc1, tNow()));
         c->sceneDirty = false;
-        c->tuneState = 0; c->tuneChoice = 0;
+        c->tuneState = 0; c->tuneChoice = 0; c->shapeState = 0; c->shapeChoice = 0; c->tuneRateBase = 0.0;
         c->sceneKey = scene_key(c);
         if (c->tuneCache != 0) {
             TuneCache& T = tune_cache();
             std::lock_guard<std::mutex> g(T.mu);
             auto it = T.choice.find(c->sceneKey);
-            if (it != T.choice.end()) { c->tuneState = 4; c->tuneChoice = it->second; }
+            if (it != T.choice.end()) { c->tuneState = 4; c->tuneChoice = it->second & 3; c->shapeState = 2; c->shapeChoice = (it->second >> 2) & 1; }
         }
         c->lateLogOff = false;      // (a new scene: its paths may be short again)
         c->wideReady = false; c->cs.wnodes.clear(); c->cs.wideDepth = 0;
@@ -473,44 +483,73 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     // Samples in flight per pass: enough rays per launch to amortise the latency-bound tail of the traversal
     // kernels, bounded by a slot budget.
     const uint32_t maxB = (uint32_t)c->maxBounces;
-    uint32_t S_ = (uint32_t)(c->samplesPerPass < 1 ? 1 : c->samplesPerPass);
-    // Slot budget: all `passStreams` buffer sets together may take half of the device's memory (the scene, the
-    // images and other tenants keep the rest), and a set at most 2^28 slots.
-    {
-        const LogShape g = log_shape(c, 1u << 20, maxB);      // (shape only: the dense / late split does not depend on the slot count)
-        const uint64_t L = (uint64_t)std::max(1, F.numLights);
-        const uint64_t lateBytes = g.lateBounces ? 4 + ((uint64_t)g.lateBounces * (sizeof(LogEntry) * L + 4) * (uint64_t)std::min(std::max(c->lateLogPercent, 1), 100) + 99) / 100 : 0;
-        const uint64_t bytesPerSlot = 2 * 32 + 2 * 16 + 8 + 16 + 16 + 4 + (uint64_t)sizeof(LogEntry) * L * g.dense + lateBytes;
-        const uint64_t wantSets = (uint64_t)std::min<int>(std::max(1, (int)c->passStreams), rt_ctx::kMaxSets);
-        uint64_t slotBudget = std::min<uint64_t>(1ull << 30, (c->deviceBytes / 100 * (uint64_t)std::min(std::max(c->pathMemPercent, 1), 90)) / (wantSets * bytesPerSlot));
-        if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
-    }
-    if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
-    // A short sample range (one rank's share of a frame split over several GPUs) is cut into at least `passStreams`
-    // passes of >= 16 samples, so that the passes still overlap on the streams.
-    if (c->autoPass != 0 && c->passStreams > 1) {
-        const uint32_t want = (r1 - r0 + (uint32_t)c->passStreams - 1) / (uint32_t)c->passStreams;
-        if (want < S_) S_ = std::max<uint32_t>(std::min<uint32_t>(16u, S_), want);
-    }
     // Samples of a pixel per wave (slot_split): 16 (of four pixels) — or all 64 of one pixel where the BVH is far larger than
     // the L2s: there the traversal kernels gain more from rays that start at one point than k_resolve loses.
     const int sampleGroup = c->sampleGroup < 0 ? (bvh_bytes(c) > kBigBvhBytes ? 6 : 4) : std::min(c->sampleGroup, 6);
-    // Whole sample groups (slot_split: 2^sampleGroup samples of a pixel share a wave), and as many passes as fill the
-    // streams evenly: 6 passes on 4 streams leave two streams idle for the last third of the frame.
-    {
-        const uint32_t n = r1 - r0;
-        uint32_t q = 1u << (uint32_t)sampleGroup;
-        while (q > 1u && q > S_) q >>= 1;
-        S_ -= S_ % q;
-        const uint32_t streams = (uint32_t)std::min<int>(std::max(1, (int)c->passStreams), rt_ctx::kMaxSets);
-        uint32_t nPasses = (n + S_ - 1) / S_;
-        if (c->autoPass != 0 && nPasses > streams && nPasses % streams != 0u) {
-            nPasses += streams - nPasses % streams;
-            uint32_t even = (n + nPasses - 1) / nPasses;
-            even = (even + q - 1) / q * q;
-            if (even >= 1u && even <= S_) S_ = even;
+    // The samples per pass of a frame rendered on `wantStreams` streams with at most `sppCap` samples per pass.
+    auto plan_pass = [&](int wantStreams, int sppCap) -> uint32_t {
+        uint32_t S_ = (uint32_t)(sppCap < 1 ? 1 : sppCap);
+        // Slot budget: all buffer sets together may take `pathMemPercent` of the device's memory (the scene, the
+        // images and other tenants keep the rest), and a set at most 2^30 slots.
+        {
+            const LogShape g = log_shape(c, 1u << 20, maxB);      // (shape only: the dense / late split does not depend on the slot count)
+            const uint64_t L = (uint64_t)std::max(1, F.numLights);
+            const uint64_t lateBytes = g.lateBounces ? 4 + ((uint64_t)g.lateBounces * (sizeof(LogEntry) * L + 4) * (uint64_t)std::min(std::max(c->lateLogPercent, 1), 100) + 99) / 100 : 0;
+            const uint64_t bytesPerSlot = 2 * 32 + 2 * 16 + 8 + 16 + 16 + 4 + (uint64_t)sizeof(LogEntry) * L * g.dense + lateBytes;
+            const uint64_t wantSets = (uint64_t)std::min<int>(std::max(1, wantStreams), rt_ctx::kMaxSets);
+            uint64_t slotBudget = std::min<uint64_t>(1ull << 30, (c->deviceBytes / 100 * (uint64_t)std::min(std::max(c->pathMemPercent, 1), 90)) / (wantSets * bytesPerSlot));
+            if ((uint64_t)S_ * sps > slotBudget) S_ = (uint32_t)std::max<uint64_t>(1, slotBudget / sps);
+        }
+        if (S_ > r1 - r0) S_ = std::max<uint32_t>(1, r1 - r0);
+        // A short sample range (one rank's share of a frame split over several GPUs) is cut into at least `wantStreams`
+        // passes of >= 16 samples, so that the passes still overlap on the streams.
+        if (c->autoPass != 0 && wantStreams > 1) {
+            const uint32_t want = (r1 - r0 + (uint32_t)wantStreams - 1) / (uint32_t)wantStreams;
+            if (want < S_) S_ = std::max<uint32_t>(std::min<uint32_t>(16u, S_), want);
+        }
+        // Whole sample groups (slot_split: 2^sampleGroup samples of a pixel share a wave), and as many passes as fill the
+        // streams evenly: 6 passes on 4 streams leave two streams idle for the last third of the frame.
+        {
+            const uint32_t n = r1 - r0;
+            uint32_t q = 1u << (uint32_t)sampleGroup;
+            while (q > 1u && q > S_) q >>= 1;
+            S_ -= S_ % q;
+            const uint32_t streams = (uint32_t)std::min<int>(std::max(1, wantStreams), rt_ctx::kMaxSets);
+            uint32_t nPasses = (n + S_ - 1) / S_;
+            if (c->autoPass != 0 && nPasses > streams && nPasses % streams != 0u) {
+                nPasses += streams - nPasses % streams;
+                uint32_t even = (n + nPasses - 1) / nPasses;
+                even = (even + q - 1) / q * q;
+                if (even >= 1u && even <= S_) S_ = even;
+            }
+        }
+        return S_;
+    };
+    const bool exact = use_exact(c);
+    const bool count = c->countVisits != 0;
+    // a frame large enough to be a measurement (config 1's 512 x 512 x 64 is)
+    const bool sizeable = (double)w * (double)h * (double)(r1 - r0) >= 1.0e7;
+    const bool tunable = !exact && !count && c->refill < 0 && c->kernelChoice < 0 && sizeable;
+    // Pass shape (see rt_ctx::shapeChoice): the caller's, a pinned one (bit 2 of kernelChoice), the measured one, or — on
+    // the frames after the kernel trial — the candidate being measured.
+    const int halfStreams = std::max(1, (int)c->passStreams / 2), wideSpp = 2 * std::max(1, (int)c->samplesPerPass);
+    bool shapeTrial = false, shapeDecidedNow = false;
+    int shape = 0;
+    if (!shape_user(c) && c->passStreams >= 2) {
+        if (c->kernelChoice >= 0) shape = (c->kernelChoice >> 2) & 1;
+        else if (c->shapeState == 2) shape = c->shapeChoice;
+        else if (tunable && c->tuneState >= 4 && c->tuneRateBase > 0.0) {
+            // (a candidate that cuts the frame exactly as the default does needs no measurement)
+            const uint32_t s0 = plan_pass(c->passStreams, c->samplesPerPass), s1 = plan_pass(halfStreams, wideSpp);
+            const uint32_t n0 = std::min<uint32_t>((r1 - r0 + s0 - 1) / s0, (uint32_t)c->passStreams), n1 = std::min<uint32_t>((r1 - r0 + s1 - 1) / s1, (uint32_t)halfStreams);
+            if (s0 == s1 && n0 == n1) { c->shapeState = 2; c->shapeChoice = 0; shapeDecidedNow = true; }
+            else { shapeTrial = true; shape = 1; c->shapeState = 1; }
         }
     }
+    const int effStreams = shape ? halfStreams : (int)c->passStreams;
+    uint32_t S_ = plan_pass(effStreams, shape ? wideSpp : (int)c->samplesPerPass);
+    // (the wider shape's sets are twice as large: the sets it does not use make room first)
+    if (shape) for (int k = effStreams; k < rt_ctx::kMaxSets; k++) if (c->set[k].hit.p) release_set(c->set[k]);
     const uint32_t lightSlots = (uint32_t)std::max(1, F.numLights);
 
     // Path buffers: `passStreams` sets of S_ samples.  When the device cannot hold them (another tenant, a smaller
@@ -521,7 +560,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     for (;;) {
         nslots = S_ * sps;
         const uint32_t nPasses = (r1 - r0 + S_ - 1) / std::max(1u, S_);
-        nSets = (int)std::max(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t)std::max(1, (int)c->passStreams), rt_ctx::kMaxSets), nPasses));
+        nSets = (int)std::max(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t)std::max(1, effStreams), rt_ctx::kMaxSets), nPasses));
         int got = 0;
         for (; got < nSets; got++)
             if ((s = ensure_paths(c, got, nslots, sps, lightSlots, maxB))) break;
@@ -534,8 +573,6 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     }
     for (int k = 0; k < nSets; k++) Pset[k] = make_paths(c, k, nslots, sps, lightSlots, maxB);
     PathBuffers P = Pset[0];
-    const bool exact = use_exact(c);
-    const bool count = c->countVisits != 0;
     SceneView S = make_view(c, exact);
     DeviceStats* dst = (DeviceStats*)c->dStats.p;
     hipStream_t st = c->stream;
@@ -566,8 +603,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     // until measured: the refill kernel for closest-hit rays (the faster one on every scene measured so far), and for
     // shadow rays too where traversal is bound by miss latency
     const int comboDefault = bigScene ? 3 : 1;
-    const bool trial = !exact && !count && c->refill < 0 && c->kernelChoice < 0 && c->tuneState < 4 &&
-                       (double)w * (double)h * (double)(r1 - r0) >= 1.0e7;      // a frame large enough to be a measurement (config 1's 512 x 512 x 64 is)
+    const bool trial = tunable && c->tuneState < 4;
     const int combo = exact ? 0 : c->refill > 0 ? 3 : c->refill == 0 ? 0 : c->kernelChoice >= 0 ? (c->kernelChoice & 3) : c->tuneState >= 4 ? c->tuneChoice
                     : trial ? kTuneTrial[c->tuneState] : comboDefault;
     const bool refillExtend = (combo & 1) != 0, refillShadow = (combo & 2) != 0;
@@ -763,13 +799,24 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                 for (int t = 0; t < 4; t++) if (c->tuneRate[t] > c->tuneRate[best]) best = t;
                 if (c->tuneRate[best] <= 1.015 * c->tuneRate[defTrial]) best = defTrial;
                 c->tuneChoice = kTuneTrial[best];
-                if (c->tuneCache != 0) {
-                    TuneCache& T = tune_cache();
-                    std::lock_guard<std::mutex> g(T.mu);
-                    T.choice[c->sceneKey] = c->tuneChoice;
-                }
+                c->tuneRateBase = c->tuneRate[best];      // (the pass-shape candidate is held against this; cached once that is decided)
+                if (shape_user(c) || c->passStreams < 2) c->shapeState = 2;
             }
         }
+    }
+    if (shapeTrial) {
+        const double rays = (double)(hs.rays_primary + hs.rays_bounce + hs.rays_shadow);
+        if (rays >= 3.0e7 && c->stats.ms_total > 0.0 && c->allocations == allocationsBefore) {
+            c->shapeChoice = rays / c->stats.ms_total > 1.02 * c->tuneRateBase ? 1 : 0;
+            c->shapeState = 2;
+            // back to the default shape: its sets are smaller and more, so all are given back and allocated afresh
+            if (!c->shapeChoice) for (int k = 0; k < rt_ctx::kMaxSets; k++) release_set(c->set[k]);
+        }
+    }
+    if ((trial || shapeTrial || shapeDecidedNow) && c->tuneState >= 4 && c->shapeState == 2 && c->tuneCache != 0) {
+        TuneCache& T = tune_cache();
+        std::lock_guard<std::mutex> g(T.mu);
+        T.choice[c->sceneKey] = c->tuneChoice | (c->shapeChoice << 2);
     }
     if (count && std::getenv("RT_DEBUG"))
         std::fprintf(stderr, "[rt] refill census: node-phase exits %llu, parked lanes/exit %.2f, free lanes/exit %.2f; reasons: parked>=triMin %llu, few nodes %llu, refill %llu, no nodes %llu; deferred %llu\n",
@@ -797,8 +844,10 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     c->stats.wide_depth = (int32_t)c->cs.wideDepth;
     { const LogShape g = log_shape(c, nslots, maxB); c->stats.log_dense_bounces = (int32_t)(g.lateBounces ? g.dense : maxB); c->stats.log_fallbacks = (int32_t)c->lateLogFallbacks; }
     // the combination the NEXT frame will run: on the frame that finishes the trial `combo` is still the last trial's
-    c->stats.kernel_choice = exact ? -2 : (trial && c->tuneState >= 4) ? c->tuneChoice : combo;
-    c->stats.kernel_choice_settled = (exact || c->refill >= 0 || c->kernelChoice >= 0 || c->tuneState >= 4) ? 1 : 0;
+    // (bit 2: the pass shape, as the next frame will have it)
+    const int shapeNext = shape_user(c) || c->passStreams < 2 ? 0 : c->kernelChoice >= 0 ? ((c->kernelChoice >> 2) & 1) : c->shapeState == 2 ? c->shapeChoice : 0;
+    c->stats.kernel_choice = exact ? -2 : (((trial && c->tuneState >= 4) ? c->tuneChoice : combo) | (shapeNext << 2));
+    c->stats.kernel_choice_settled = (exact || c->refill >= 0 || c->kernelChoice >= 0 || (c->tuneState >= 4 && (c->shapeState == 2 || shape_user(c) || c->passStreams < 2))) ? 1 : 0;
     c->primValid = aov;
     return RT_OK;
 }
@@ -939,7 +988,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "traversalMode")) c->traversalMode = v;
     else if (name_is(name, "timeKernels")) c->timeKernels = v;
     else if (name_is(name, "countVisits")) c->countVisits = v;
-    else if (name_is(name, "samplesPerPass")) c->samplesPerPass = v;
+    else if (name_is(name, "samplesPerPass")) { c->samplesPerPass = v < 1 ? 64 : v; c->sppUser = v >= 1 && v != 64; }      // < 1: back to the default
     else if (name_is(name, "sampleGroup")) c->sampleGroup = v;
     else if (name_is(name, "pathMemPercent")) c->pathMemPercent = v;
     else if (name_is(name, "logDenseBounces")) { c->logDenseBounces = v; c->lateLogOff = false; }
@@ -954,11 +1003,11 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "wideNodes")) c->wideNodes = v;
     else if (name_is(name, "sunKernel")) c->sunKernel = v;
     else if (name_is(name, "tuneCache")) c->tuneCache = v;
-    else if (name_is(name, "kernelChoice")) c->kernelChoice = v < 0 ? -1 : (v & 3);
+    else if (name_is(name, "kernelChoice")) c->kernelChoice = v < 0 ? -1 : (v & 7);      // bits 0, 1: kernels; bit 2: pass shape
     else if (name_is(name, "refillBlocksPerCU")) c->refillBlocksPerCU = v < 0 ? 0 : v;
     else if (name_is(name, "autoPass")) c->autoPass = v;
     else if (name_is(name, "fusePairs")) c->fusePairs = v;
-    else if (name_is(name, "passStreams")) c->passStreams = v < 1 ? 4 : v;      // < 1: back to the default
+    else if (name_is(name, "passStreams")) { c->passStreams = v < 1 ? 4 : v; c->streamsUser = v >= 1; }      // < 1: back to the default (and to the measured pass shape)
     return RT_OK;   // unknown names are ignored (glGetUniformLocation == -1)
 }
 rt_status rt_set_float(rt_ctx* c, const char* name, float v) {
