@@ -375,7 +375,7 @@ def test_full_size_frame_is_reproducible_and_stream_independent(oracle_lib, scen
     cs.dispatch()
     assert np.array_equal(bits(cs.get_image(0)), bits(first))
     for knobs in ({"passStreams": 1}, {"passStreams": 3, "samplesPerPass": 7, "autoPass": 0}, {"refill": 1}, {"blocksPerCU": 5},
-                  {"kernelChoice": 2}, {"kernelChoice": 1}):
+                  {"kernelChoice": 2}, {"kernelChoice": 1}, {"kernelChoice": 5}):      # (5: bit 2 = half the streams, twice the samples per pass)
         for k, v in knobs.items():
             cs.setInt(k, v)
         cs.dispatch()

@@ -218,6 +218,33 @@ def test_several_lights_bit_exact(oracle_lib, models_root, scene_id, knobs):
     cs.Delete()
 
 
+@pytest.mark.parametrize("knobs", [{}, {"refill": 1}, {"traversalMode": 1}])
+def test_light_of_a_type_the_shader_does_not_know(oracle_lib, models_root, knobs):
+    """shader.comp:462-483 casts a shadow ray for lightType 0 and 1 only; a light of any other type keeps dirToLight = 0,
+    so N.L = 0 and it adds nothing.  The contribution log has no state word: which entries await a shadow ray is read off
+    the light's type and the entry itself (non-zero), so such a light between a point light and a sun must neither be
+    traced nor disturb its neighbours' entries.  All four images and the ray counts against the oracle."""
+    from oracle import gltf_flatten as G
+    from raytracing_amd import ComputeShader
+    lights = [MULTI_LIGHTS[0], ((1.0, 5.0, 2.0), (0.0, -1.0, 0.0), 2, 50.0), MULTI_LIGHTS[1]]
+    flat = G.load_scene(models_root, 4)
+    flat["lights"], flat["hasSun"] = G.lights_to_gpu(lights)
+    sc = oracle_lib.Scene(flat)
+    W, H, spp, b = 72, 40, 3, 5
+    want = oracle_lib.render(sc, oracle_lib.make_params(sc, W, H, spp, b, math_mode=1))
+    cs = ComputeShader()
+    setup_core(cs, sc, W, H, spp, b)
+    for k, v in knobs.items():
+        cs.setInt(k, v)
+    cs.dispatch()
+    for k, name in enumerate(("color", "albedo", "normal", "depth")):
+        bad = ~same_floats(cs.get_image(k), want[name])
+        assert not bad.any(), "%s: %d floats differ" % (name, int(bad.sum()))
+    st, ost = cs.stats(), want["stats"]
+    assert st["rays_shadow"] + st["rays_shadow_skipped"] == ost["rays_shadow"]
+    cs.Delete()
+
+
 @pytest.mark.parametrize("knobs", [{}, {"refill": 1}, {"logDenseBounces": 1, "lateLogPercent": 100}])
 def test_ten_lights_bit_exact(oracle_lib, models_root, knobs):
     """More lights than the copy in the kernel argument segment holds (8): the rest are read from slot 5."""

@@ -13,13 +13,15 @@
 // MODE 7: 4 x dwordx4, the 4 lanes of a quad reading the 4 words of one 64-B record (coalesced 64-B requests)
 // MODE 8: MODE 0 with a 32-bit byte offset from a wave-uniform base (global_load ... v_off, s[base])   MODE 9: MODE 0 as raw buffer loads
 // MODE 10: MODE 0 with the first word's load completed (s_waitcnt) before the other three are issued (do in-flight misses to one line merge?)
+// MODE 11: odd lanes 4 x ds_read_b128 from the LDS copy, even lanes 4 x dwordx4 from the table (do the two pipes overlap?)
+// MODE 12: as 11 with three lanes of four on the LDS copy
 // MODE 5: 8 x dwordx4 from one 128-B record per lane (a whole cache line: a 4-wide node)   MODE 6: 3 x dwordx4 at 48-B stride (a triangle record)
 __device__ __forceinline__ float sum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(const float4* __restrict__ table, uint32_t nrec, int iters, int activeLanes, int uniform, float* out) {
-    __shared__ float4 lds[MODE == 3 ? 2048 * 4 : 1];
-    if (MODE == 3) { for (uint32_t i = threadIdx.x; i < 2048 * 4; i += 256) lds[i] = table[i % (nrec * 4)]; __syncthreads(); }
+    __shared__ float4 lds[(MODE == 3 || MODE == 11 || MODE == 12) ? 2048 * 4 : 1];
+    if (MODE == 3 || MODE == 11 || MODE == 12) { for (uint32_t i = threadIdx.x; i < 2048 * 4; i += 256) lds[i] = table[i % (nrec * 4)]; __syncthreads(); }
     uint32_t lane = threadIdx.x & 63;
     uint32_t x = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
     float acc = 0.f;
@@ -49,6 +51,11 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ table, uint3
                 a = ld(0); b = ld(16); c = ld(32); d = ld(48); acc += sum4(a) + sum4(b) + sum4(c) + sum4(d); }
             else if (MODE == 10) { const float4* p = table + (size_t)r * 4; a = p[0]; asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) :: "memory");
                 b = p[1]; c = p[2]; d = p[3]; acc += sum4(a) + sum4(b) + sum4(c) + sum4(d); }
+            else if (MODE == 11 || MODE == 12) {
+                const bool inLds = MODE == 11 ? (lane & 1u) != 0u : (lane & 3u) != 0u;
+                if (inLds) { const float4* p = lds + (r & 2047) * 4; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
+                else { const float4* p = table + (size_t)r * 4; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
+                acc += sum4(a) + sum4(b) + sum4(c) + sum4(d); }
             else if (MODE == 6) { const float4* p = table + (size_t)r * 3; a = p[0]; b = p[1]; c = p[2]; acc += sum4(a) + sum4(b) + sum4(c); }
             // dependent chain like a traversal: next index depends on the data
             x += (uint32_t)(acc != 12345.678f);
@@ -83,6 +90,13 @@ int main() {
     float4* table; float* out;
     CHK(hipMalloc(&table, nrec * 64)); CHK(hipMalloc(&out, 256 * 8 * 256 * 4));
     CHK(hipMemcpy(table, h.data(), nrec * 64, hipMemcpyHostToDevice));
+    if (getenv("UBENCH_MIXED_ONLY")) {
+        run<0>("4 x global_load_dwordx4", table, nrec, out, 4);
+        run<3>("4 x ds_read_b128", table, nrec, out, 4);
+        run<11>("mixed: 1/2 LDS, 1/2 global", table, nrec, out, 4);
+        run<12>("mixed: 3/4 LDS, 1/4 global", table, nrec, out, 4);
+        return 0;
+    }
     run<0>("4 x global_load_dwordx4", table, nrec, out, 4);
     run<4>("2 x global_load_dwordx4", table, nrec, out, 2);
     run<1>("1 x global_load_dwordx4", table, nrec, out, 1);
