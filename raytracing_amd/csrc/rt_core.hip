@@ -111,7 +111,12 @@ struct rt_ctx {
     // path state
     // Up to kMaxSets sets of per-pass path buffers: consecutive passes run on `passStreams` streams, so that the small, tail-dominated
     // launches of one pass's late bounces overlap the large launches of the next pass (only k_resolve is ordered).
-    struct PathSet { DevBuf ray[2], rayS[2], hit, shadowRec, shadeLoc, contrib, depth, counters, overflow, late, lateNext, lateHead; };
+    // The per-slot arrays of ALL sets live in one allocation per array (set k's part starts at k x the set's size): the
+    // same memory serves four sets of S samples and two sets of 2 S, so trying and switching the pass shape allocates nothing
+    // (hipFree + hipMalloc of ~100 GB cost seconds).  Per set: the queue counters and the traversal-stack overflow area.
+    enum { A_RAY0, A_RAY1, A_RAYS0, A_RAYS1, A_HIT, A_SHADOWREC, A_SHADELOC, A_CONTRIB, A_DEPTH, A_LATE, A_LATENEXT, A_LATEHEAD, A_COUNT };
+    DevBuf arena[A_COUNT];
+    struct PathSet { DevBuf counters, overflow; };
     static constexpr int kMaxSets = 8;
     PathSet set[kMaxSets];
     DevBuf accum, dStats;
@@ -375,9 +380,9 @@ uint32_t overflow_depth(rt_ctx* c) {
     return (uint32_t)need;
 }
 
-void release_set(rt_ctx::PathSet& ps) {
-    DevBuf* pb[] = {&ps.ray[0], &ps.ray[1], &ps.rayS[0], &ps.rayS[1], &ps.hit, &ps.shadowRec, &ps.shadeLoc, &ps.contrib, &ps.depth, &ps.counters, &ps.overflow, &ps.late, &ps.lateNext, &ps.lateHead};
-    for (DevBuf* b : pb) b->release();
+void release_paths(rt_ctx* c) {
+    for (DevBuf& b : c->arena) b.release();
+    for (auto& ps : c->set) { ps.counters.release(); ps.overflow.release(); }
 }
 
 // The contribution log of a pass: planes [0, dense) hold an entry per slot; the bounces from `dense` on, which few paths
@@ -396,42 +401,63 @@ LogShape log_shape(rt_ctx* c, uint32_t nslots, uint32_t maxBounces) {
     return g;
 }
 
-rt_status ensure_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
-    rt_status s;
-    size_t n = nslots;
-    rt_ctx::PathSet& ps = c->set[which];
-    if ((s = ensure(c, ps.overflow, (size_t)overflow_depth(c) * stack_blocks(c, nslots) * RT_BLOCK * sizeof(uint2)))) return s;
-    for (int k = 0; k < 2; k++) {
-        if ((s = ensure(c, ps.ray[k], n * 32))) return s;
-        if ((s = ensure(c, ps.rayS[k], n * 16))) return s;
-    }
-    if ((s = ensure(c, ps.shadowRec, n * 16))) return s;
-    if ((s = ensure(c, ps.shadeLoc, n * 16))) return s;
-    if ((s = ensure(c, ps.hit, n * 8))) return s;
+// Bytes of one set's part of every arena array (multiples of 256, so that every set's part is aligned).
+struct SetBytes { size_t b[rt_ctx::A_COUNT]; };
+SetBytes set_bytes(rt_ctx* c, uint32_t nslots, uint32_t lightSlots, uint32_t maxBounces) {
+    SetBytes sb;
+    const size_t n = nslots;
     const LogShape g = log_shape(c, nslots, maxBounces);
-    if ((s = ensure(c, ps.contrib, n * sizeof(LogEntry) * lightSlots * g.dense))) return s;
-    if (g.lateBounces) {
-        if ((s = ensure(c, ps.late, (size_t)g.lateBounces * lightSlots * g.lateCap * sizeof(LogEntry)))) return s;
-        if ((s = ensure(c, ps.lateNext, (size_t)g.lateBounces * g.lateCap * 4))) return s;
-        if ((s = ensure(c, ps.lateHead, n * 4))) return s;
+    sb.b[rt_ctx::A_RAY0] = sb.b[rt_ctx::A_RAY1] = n * 32;
+    sb.b[rt_ctx::A_RAYS0] = sb.b[rt_ctx::A_RAYS1] = n * 16;
+    sb.b[rt_ctx::A_HIT] = n * 8;
+    sb.b[rt_ctx::A_SHADOWREC] = n * 16;
+    sb.b[rt_ctx::A_SHADELOC] = n * 16;
+    sb.b[rt_ctx::A_CONTRIB] = n * sizeof(LogEntry) * lightSlots * g.dense;
+    sb.b[rt_ctx::A_DEPTH] = n * 4;
+    sb.b[rt_ctx::A_LATE] = g.lateBounces ? (size_t)g.lateBounces * lightSlots * g.lateCap * sizeof(LogEntry) : 0;
+    sb.b[rt_ctx::A_LATENEXT] = g.lateBounces ? (size_t)g.lateBounces * g.lateCap * 4 : 0;
+    sb.b[rt_ctx::A_LATEHEAD] = g.lateBounces ? n * 4 : 0;
+    for (size_t& x : sb.b) x = (x + 255) / 256 * 256;
+    return sb;
+}
+
+// Path buffers for `nSets` sets of `nslots` slots; `alsoSets` x `alsoSlots` (0: none) is a second pass shape the arena has
+// to hold as well (the candidate of the pass-shape trial), so that switching between the two allocates nothing.
+rt_status ensure_paths(rt_ctx* c, int nSets, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces,
+                       int alsoSets = 0, uint32_t alsoSlots = 0) {
+    rt_status s;
+    const SetBytes sb = set_bytes(c, nslots, lightSlots, maxBounces);
+    SetBytes also;
+    if (alsoSets > 0) also = set_bytes(c, alsoSlots, lightSlots, maxBounces);
+    for (int a = 0; a < rt_ctx::A_COUNT; a++) {
+        size_t need = sb.b[a] * (size_t)nSets;
+        if (alsoSets > 0) need = std::max(need, also.b[a] * (size_t)alsoSets);
+        if (need && (s = ensure(c, c->arena[a], need))) return s;
     }
-    if ((s = ensure(c, ps.depth, n * 4))) return s;
+    const uint32_t mostSlots = std::max(nslots, alsoSets > 0 ? alsoSlots : 0u);
+    for (int k = 0; k < std::max(nSets, alsoSets); k++) {
+        if ((s = ensure(c, c->set[k].overflow, (size_t)overflow_depth(c) * stack_blocks(c, mostSlots) * RT_BLOCK * sizeof(uint2)))) return s;
+        if ((s = ensure(c, c->set[k].counters, (size_t)(2 * (maxBounces + 1)) * 4))) return s;
+    }
     if ((s = ensure(c, c->accum, (size_t)slotsPerSample * 16))) return s;
-    if ((s = ensure(c, ps.counters, (size_t)(2 * (maxBounces + 1)) * 4))) return s;
     if ((s = ensure(c, c->dStats, sizeof(DeviceStats)))) return s;
     return RT_OK;
 }
 
 PathBuffers make_paths(rt_ctx* c, int which, uint32_t nslots, uint32_t slotsPerSample, uint32_t lightSlots, uint32_t maxBounces) {
     PathBuffers P;
+    const SetBytes sb = set_bytes(c, nslots, lightSlots, maxBounces);
+    auto part = [&](int a) -> void* { return c->arena[a].p ? (char*)c->arena[a].p + sb.b[a] * (size_t)which : nullptr; };
     rt_ctx::PathSet& ps = c->set[which];
-    for (int k = 0; k < 2; k++) { P.ray[k] = (float4*)ps.ray[k].p; P.rayS[k] = (float4*)ps.rayS[k].p; }
-    P.hit = (float2*)ps.hit.p; P.shadowRec = (float4*)ps.shadowRec.p; P.shadeLoc = (float4*)ps.shadeLoc.p;
-    P.contrib = (LogEntry*)ps.contrib.p; P.depth = (uint32_t*)ps.depth.p; P.accum = (float4*)c->accum.p;
+    P.ray[0] = (float4*)part(rt_ctx::A_RAY0); P.ray[1] = (float4*)part(rt_ctx::A_RAY1);
+    P.rayS[0] = (float4*)part(rt_ctx::A_RAYS0); P.rayS[1] = (float4*)part(rt_ctx::A_RAYS1);
+    P.hit = (float2*)part(rt_ctx::A_HIT); P.shadowRec = (float4*)part(rt_ctx::A_SHADOWREC); P.shadeLoc = (float4*)part(rt_ctx::A_SHADELOC);
+    P.contrib = (LogEntry*)part(rt_ctx::A_CONTRIB); P.depth = (uint32_t*)part(rt_ctx::A_DEPTH); P.accum = (float4*)c->accum.p;
     P.counters = (uint32_t*)ps.counters.p;
     P.nslots = nslots; P.slotsPerSample = slotsPerSample; P.lightSlots = lightSlots; P.grpShift = 0;
     const LogShape g = log_shape(c, nslots, maxBounces);
-    P.late = (LogEntry*)ps.late.p; P.lateNext = (uint32_t*)ps.lateNext.p; P.lateHead = (uint32_t*)ps.lateHead.p;
+    P.late = g.lateBounces ? (LogEntry*)part(rt_ctx::A_LATE) : nullptr; P.lateNext = g.lateBounces ? (uint32_t*)part(rt_ctx::A_LATENEXT) : nullptr;
+    P.lateHead = g.lateBounces ? (uint32_t*)part(rt_ctx::A_LATEHEAD) : nullptr;
     P.denseBounces = g.lateBounces ? g.dense : 0xffffffffu; P.lateCap = g.lateCap;
     P.overflow = (uint2*)ps.overflow.p; P.overflowStride = stack_blocks(c, nslots) * RT_BLOCK; P.overflowDepth = overflow_depth(c);
     return P;
@@ -548,8 +574,10 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     }
     const int effStreams = shape ? halfStreams : (int)c->passStreams;
     uint32_t S_ = plan_pass(effStreams, shape ? wideSpp : (int)c->samplesPerPass);
-    // (the wider shape's sets are twice as large: the sets it does not use make room first)
-    if (shape) for (int k = effStreams; k < rt_ctx::kMaxSets; k++) if (c->set[k].hit.p) release_set(c->set[k]);
+    // While the shape is undecided the arena is sized for both, so that trying the other one allocates nothing.
+    const bool bothShapes = !shape_user(c) && c->passStreams >= 2 && c->kernelChoice < 0 && c->shapeState < 2 && tunable;
+    const int otherStreams = shape ? (int)c->passStreams : halfStreams;
+    const uint32_t otherS = bothShapes ? plan_pass(otherStreams, shape ? (int)c->samplesPerPass : wideSpp) : 0u;
     const uint32_t lightSlots = (uint32_t)std::max(1, F.numLights);
 
     // Path buffers: `passStreams` sets of S_ samples.  When the device cannot hold them (another tenant, a smaller
@@ -557,20 +585,26 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     uint32_t nslots = 0;
     int nSets = 1;
     PathBuffers Pset[rt_ctx::kMaxSets];
+    int capSets = std::min<int>(std::max(1, effStreams), rt_ctx::kMaxSets);
+    bool roomForBoth = bothShapes;
     for (;;) {
         nslots = S_ * sps;
         const uint32_t nPasses = (r1 - r0 + S_ - 1) / std::max(1u, S_);
-        nSets = (int)std::max(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t)std::max(1, effStreams), rt_ctx::kMaxSets), nPasses));
-        int got = 0;
-        for (; got < nSets; got++)
-            if ((s = ensure_paths(c, got, nslots, sps, lightSlots, maxB))) break;
-        if (got == nSets) break;
+        nSets = (int)std::max(1u, std::min<uint32_t>((uint32_t)capSets, nPasses));
+        int alsoSets = 0; uint32_t alsoSlots = 0;
+        if (roomForBoth && otherS > 0) {
+            alsoSlots = otherS * sps;
+            alsoSets = (int)std::max(1u, std::min<uint32_t>((uint32_t)std::min<int>(std::max(1, otherStreams), rt_ctx::kMaxSets), (r1 - r0 + otherS - 1) / otherS));
+        }
+        if (!(s = ensure_paths(c, nSets, nslots, sps, lightSlots, maxB, alsoSets, alsoSlots))) break;
         (void)hipGetLastError();
-        release_set(c->set[got]);
-        if (got >= 1) { nSets = got; break; }
+        release_paths(c);
+        if (roomForBoth) { roomForBoth = false; continue; }      // first without the room for the other shape
+        if (nSets > 1) { capSets = nSets - 1; continue; }         // then fewer streams
         if (S_ <= 1) return s;
-        S_ = std::max(1u, S_ / 2);
+        S_ = std::max(1u, S_ / 2);                                // then fewer samples in flight
     }
+    if (bothShapes && !roomForBoth) { c->shapeState = 2; c->shapeChoice = 0; shapeTrial = false; }      // (no room to hold both shapes: the default stays)
     for (int k = 0; k < nSets; k++) Pset[k] = make_paths(c, k, nslots, sps, lightSlots, maxB);
     PathBuffers P = Pset[0];
     SceneView S = make_view(c, exact);
@@ -809,8 +843,6 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
         if (rays >= 3.0e7 && c->stats.ms_total > 0.0 && c->allocations == allocationsBefore) {
             c->shapeChoice = rays / c->stats.ms_total > 1.02 * c->tuneRateBase ? 1 : 0;
             c->shapeState = 2;
-            // back to the default shape: its sets are smaller and more, so all are given back and allocated afresh
-            if (!c->shapeChoice) for (int k = 0; k < rt_ctx::kMaxSets; k++) release_set(c->set[k]);
         }
     }
     if ((trial || shapeTrial || shapeDecidedNow) && c->tuneState >= 4 && c->shapeState == 2 && c->tuneCache != 0) {
@@ -950,7 +982,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t x : c->extra) if (x) (void)hipStreamSynchronize(x);
-    for (auto& ps : c->set) release_set(ps);
+    release_paths(c);
     for (hipEvent_t ev : c->evResolve) if (ev) (void)hipEventDestroy(ev);
     if (c->evInit) (void)hipEventDestroy(c->evInit);
     for (hipStream_t x : c->extra) if (x) (void)hipStreamDestroy(x);
@@ -1185,7 +1217,7 @@ rt_status rt_trace_rays(rt_ctx* c, const float* origins, const float* dirs, uint
     if (!hadLights) c->slotSet[RT_SLOT_LIGHTS] = false;
     if (s) return s;
     uint32_t nslots = (uint32_t)((n + 63) / 64 * 64);
-    if ((s = ensure_paths(c, 0, nslots, nslots, 1, 1))) return s;
+    if ((s = ensure_paths(c, 1, nslots, nslots, 1, 1))) return s;
     PathBuffers P = make_paths(c, 0, nslots, nslots, 1, 1);
     const bool exact = use_exact(c);
     const bool count = c->countVisits != 0;
