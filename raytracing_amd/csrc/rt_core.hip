@@ -125,6 +125,7 @@ struct rt_ctx {
     int32_t passStreams = 4, autoPass = 1, fusePairs = 1;
     // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill 0 = never, 1 = always, -1 = chosen per scene.
     int32_t refill = -1, refillIdle = 16, refillNodeMin = 28, refillBlocksPerCU = 0;
+    int32_t refillFromBounce = 1;   // closest-hit rays of bounces below this use the batch kernel even where the refill kernel was chosen (camera rays always do)
     int32_t refillTriMin = 0, refillNodeLow = 0, refillDefer = 0;   // 0 = the kernels' defaults (rt_trace_refill.hip.h, RefillSched)   // refillBlocksPerCU 0 = automatic (refill_blocks)
     // refill = -1: which traversal kernels are faster depends on the scene, and not the same way for closest-hit and
     // shadow rays (closest hit: the refill kernel on every scene measured; shadow rays: the one-sun batch kernel and the
@@ -640,7 +641,8 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
     const bool trial = tunable && c->tuneState < 4;
     const int combo = exact ? 0 : c->refill > 0 ? 3 : c->refill == 0 ? 0 : c->kernelChoice >= 0 ? (c->kernelChoice & 3) : c->tuneState >= 4 ? c->tuneChoice
                     : trial ? kTuneTrial[c->tuneState] : comboDefault;
-    const bool refillExtend = (combo & 1) != 0, refillShadow = (combo & 2) != 0;
+    const bool refillExtendAll = (combo & 1) != 0, refillShadow = (combo & 2) != 0;
+    const bool refillExtend = refillExtendAll;
     const bool wide = S.wnodes != nullptr;
     const int refillIdle = std::min(64, std::max(1, (int)c->refillIdle));
     const int refillNodeMin = std::min(64, std::max(1, (int)c->refillNodeMin)) | (std::min(64, std::max(0, (int)c->refillTriMin)) << 8) |
@@ -710,7 +712,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             rt_ctx::EvPair* e = nullptr;
             if (!extendDone) {
                 e = evBegin(b == 0 ? 3 : 0);
-                if (refillExtend && b > 0) {      // camera rays are coherent: the batch kernel is the better one there
+                if (refillExtend && b > 0 && (int)b >= c->refillFromBounce) {      // camera rays are coherent: the batch kernel is the better one there
                     const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
                     if (wide) {
                         if (count) k_extend_refill<true, false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, qin, (const uint32_t*)(qcount + b), (int)rBase, 0u, refillIdle, refillNodeMin, dst);
@@ -742,6 +744,7 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
             if (F.numLights > 0) {
                 if (pairs && b + 1 < maxB) {
                     const uint32_t rg = refill_blocks(c, Pp.nslots, nSets);
+                    const bool refillExtend = refillExtendAll && (int)(b + 1) >= c->refillFromBounce;      // (this launch's closest-hit rays are bounce b + 1's)
                     const uint32_t gE = refillExtend ? rg : tb, gS = refillShadow ? rg : tb;
                     const dim3 g(std::max(gE, gS));
                     const float4* qnext = P.ray[(b + 1) & 1];
@@ -1028,6 +1031,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "blocksPerCU")) c->blocksPerCU = v < 1 ? 1 : v;
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
+    else if (name_is(name, "refillFromBounce")) c->refillFromBounce = v < 1 ? 1 : v;
     else if (name_is(name, "refillNodeMin")) c->refillNodeMin = v;
     else if (name_is(name, "refillTriMin")) c->refillTriMin = v;
     else if (name_is(name, "refillNodeLow")) c->refillNodeLow = v;

@@ -36,7 +36,7 @@ struct PathBuffers {
     // and write it with dense, coalesced accesses instead of gathers through a queue of slot ids (the scattered
     // 16-byte accesses into multi-GB arrays were HBM round trips on every ray).  Two buffers alternate by bounce parity.
     float4* ray[2];      // entry i: [2i] = (o.xyz, d.x), [2i+1] = (d.y, d.z, flag bits (bit0 refracting), slot bits)
-    float4* rayS[2];     // entry i: strength.xyz
+    float4* rayS[2];     // entry i: strength.xyz, slot bits (a path that left the scene needs nothing else of its state)
     float2* hit;         // entry i of the bounce being traced: (t, reference triangle index bits: -1 miss, -2 dead slot);
                          // hitLoc = o + d * t is recomputed by k_shade
     float4* shadowRec;   // shadow-queue entry j: (origin.xyz, slot bits)
@@ -892,13 +892,13 @@ __global__ __launch_bounds__(RT_BLOCK, (TEX ? 3 : 4)) void k_shade(SceneView S, 
         const int ref = __float_as_int(h2.y);
         // A path that left the scene (or a dead slot) needs next to nothing — and on the benchmark scenes more than half of
         // the paths of every bounce are misses.  Bounce 0: the camera ray is not regenerated at all (the depth word alone says
-        // "sky", k_resolve adds the constant; the primary-hit tap was preset to -1).  Later bounces: strength and slot are
-        // read, the ray's origin / direction and the pixel decode (three integer divisions) are not.
+        // "sky", k_resolve adds the constant; the primary-hit tap was preset to -1).  Later bounces: one 16-byte record, strength
+        // and slot, is read; the ray's origin / direction and the pixel decode (three integer divisions) are not.
         if (live && ref < 0) {
             if (bounce == 0) P.depth[slot] = ref == -2 ? 0u : (1u | RT_DEPTH_MISS0);
             else {
                 const float4 s4 = raySIn[i];
-                slot = __float_as_uint(raysIn[2u * i + 1u].w);
+                slot = __float_as_uint(s4.w);
                 const uint32_t logIdx = lateB ? i : slot;
                 if (LATE && (uint32_t)bounce == P.denseBounces) P.lateHead[slot] = i;
                 if (ref != -2) {
@@ -971,7 +971,7 @@ __global__ __launch_bounds__(RT_BLOCK, (TEX ? 3 : 4)) void k_shade(SceneView S, 
                   const uint32_t o = idx[0][k];
                   raysOut[2u * o] = a;
                   raysOut[2u * o + 1u] = make_float4(b.x, b.y, __uint_as_float(((refrMask >> k) & 1u) ? RT_FLAG_REFRACTING : 0u), sl);
-                  raySOut[o] = make_float4(b.z, b.w, stageC[st], 0.f);
+                  raySOut[o] = make_float4(b.z, b.w, stageC[st], sl);
               }
               if (flag[1][k]) P.shadowRec[idx[1][k]] = make_float4(a.x, a.y, a.z, lateB ? __uint_as_float(ik) : sl);
           }
