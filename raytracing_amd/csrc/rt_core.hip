@@ -125,6 +125,12 @@ struct rt_ctx {
     int32_t passStreams = 4, autoPass = 1, fusePairs = 1;
     // dynamic-fetch traversal kernels (rt_trace_refill.hip.h): refill 0 = never, 1 = always, -1 = chosen per scene.
     int32_t refill = -1, refillIdle = 16, refillNodeMin = 28, refillBlocksPerCU = 0;
+    // The sun's shadow rays of the first `packetBounces` bounces are traced by the packet kernel (a wave walks the tree once
+    // for 64 consecutive rays, scalar loads; rt_trace_packet.hip.h): bounce 0's start at the camera-ray hits of a few pixels.
+    // -1: bounce 0 where the compact BVH is at most 1 MB — a packet step is one dependent scalar-load round trip per wave,
+    // which pays while the tree sits in every L2 (scene 4: frame -0.7 %, those rays -11 %) and not beyond (scene 7 +-0,
+    // the 20 M-triangle field +-0 for bounce 0 and +60 % on the shadow rays with bounce 1 included).
+    int32_t packetBounces = -1;
     int32_t refillFromBounce = 1;   // closest-hit rays of bounces below this use the batch kernel even where the refill kernel was chosen (camera rays always do)
     int32_t refillTriMin = 0, refillNodeLow = 0, refillDefer = 0;   // 0 = the kernels' defaults (rt_trace_refill.hip.h, RefillSched)   // refillBlocksPerCU 0 = automatic (refill_blocks)
     // refill = -1: which traversal kernels are faster depends on the scene, and not the same way for closest-hit and
@@ -204,7 +210,11 @@ const size_t kRecordSize[6] = {80, 64, 80, 48, 128, 48};
 // BVHs this much larger than the L2s (32 MB) are traversed out of the Infinity Cache and HBM: the refill kernels and the
 // two-level nodes are their defaults
 constexpr size_t kBigBvhBytes = (size_t)64 << 20;
+constexpr size_t kSmallBvhBytes = (size_t)1 << 20;
+size_t bvh_bytes(const rt_ctx* c);
+int packet_bounces(const rt_ctx* c);
 size_t bvh_bytes(const rt_ctx* c) { return c->cs.nodes.size() * sizeof(CNode) + (size_t)c->cs.nTris * sizeof(CTri); }
+int packet_bounces(const rt_ctx* c) { return c->packetBounces >= 0 ? (int)c->packetBounces : (bvh_bytes(c) <= kSmallBvhBytes ? 1 : 0); }
 bool shape_user(const rt_ctx* c) { return c->streamsUser || c->sppUser; }      // the caller chose the pass shape: no trial of it
 bool want_wide(const rt_ctx* c) { return c->wideNodes > 0 || (c->wideNodes < 0 && bvh_bytes(c) > kBigBvhBytes); }
 
@@ -745,21 +755,23 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                 if (pairs && b + 1 < maxB) {
                     const uint32_t rg = refill_blocks(c, Pp.nslots, nSets);
                     const bool refillExtend = refillExtendAll && (int)(b + 1) >= c->refillFromBounce;      // (this launch's closest-hit rays are bounce b + 1's)
-                    const uint32_t gE = refillExtend ? rg : tb, gS = refillShadow ? rg : tb;
-                    const dim3 g(std::max(gE, gS));
+                    const uint32_t gE = refillExtend ? rg : tb; uint32_t gS = refillShadow ? rg : tb;
                     const float4* qnext = P.ray[(b + 1) & 1];
                     const uint32_t* cE = qcount + b + 1;
                     const uint32_t* cS = scount + b;
-                    const int shd = refillShadow ? (sun1 ? 3 : 2) : (sun1 ? 1 : 0);
+                    const bool packet = sun1 && (int)b < packet_bounces(c);
+                    const int shd = packet ? 4 : refillShadow ? (sun1 ? 3 : 2) : (sun1 ? 1 : 0);
+                    if (packet) gS = tb;
+                    const dim3 g(std::max(gE, gS));
                     e = evBegin(0);
 #define RT_PAIR(EXT, SHD) k_trace_pair<EXT, SHD><<<g, RT_BLOCK, 0, st>>>(S, F, Pp, qnext, cE, (int)rBase, cS, (int)b, gE, gS, refillIdle, refillNodeMin, dst)
 #define RT_PAIRW(EXT, SHD) k_trace_pair<EXT, SHD, true><<<g, RT_BLOCK, 0, st>>>(S, F, Pp, qnext, cE, (int)rBase, cS, (int)b, gE, gS, refillIdle, refillNodeMin, dst)
-                    if (wide && (refillExtend || refillShadow)) {
-                        if (refillExtend) { if (shd == 0) RT_PAIRW(1, 0); else if (shd == 1) RT_PAIRW(1, 1); else if (shd == 2) RT_PAIRW(1, 2); else RT_PAIRW(1, 3); }
+                    if (wide && (refillExtend || (refillShadow && shd != 4))) {
+                        if (refillExtend) { if (shd == 0) RT_PAIRW(1, 0); else if (shd == 1) RT_PAIRW(1, 1); else if (shd == 2) RT_PAIRW(1, 2); else if (shd == 3) RT_PAIRW(1, 3); else RT_PAIRW(1, 4); }
                         else { if (shd == 2) RT_PAIRW(0, 2); else RT_PAIRW(0, 3); }
                     }
-                    else if (refillExtend) { if (shd == 0) RT_PAIR(1, 0); else if (shd == 1) RT_PAIR(1, 1); else if (shd == 2) RT_PAIR(1, 2); else RT_PAIR(1, 3); }
-                    else { if (shd == 0) RT_PAIR(0, 0); else if (shd == 1) RT_PAIR(0, 1); else if (shd == 2) RT_PAIR(0, 2); else RT_PAIR(0, 3); }
+                    else if (refillExtend) { if (shd == 0) RT_PAIR(1, 0); else if (shd == 1) RT_PAIR(1, 1); else if (shd == 2) RT_PAIR(1, 2); else if (shd == 3) RT_PAIR(1, 3); else RT_PAIR(1, 4); }
+                    else { if (shd == 0) RT_PAIR(0, 0); else if (shd == 1) RT_PAIR(0, 1); else if (shd == 2) RT_PAIR(0, 2); else if (shd == 3) RT_PAIR(0, 3); else RT_PAIR(0, 4); }
 #undef RT_PAIR
 #undef RT_PAIRW
                     evEnd(e);
@@ -768,7 +780,9 @@ rt_status render_region(rt_ctx* c, uint32_t x, uint32_t y, uint32_t w, uint32_t 
                     continue;
                 }
                 e = evBegin(2);
-                if (refillShadow) {
+                if (!exact && !count && sun1 && (int)b < packet_bounces(c))
+                    k_shadow_sun_packet<<<tb, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b);
+                else if (refillShadow) {
                     const dim3 rg(refill_blocks(c, Pp.nslots, nSets));
                     if (wide) {
                         if (count) k_shadow_refill<true, false, true><<<rg, RT_BLOCK, 0, st>>>(S, F, Pp, (const uint32_t*)(scount + b), (int)b, refillIdle, refillNodeMin, dst);
@@ -1032,6 +1046,7 @@ rt_status rt_set_int(rt_ctx* c, const char* name, int32_t v) {
     else if (name_is(name, "refill")) c->refill = v;
     else if (name_is(name, "refillIdle")) c->refillIdle = v;
     else if (name_is(name, "refillFromBounce")) c->refillFromBounce = v < 1 ? 1 : v;
+    else if (name_is(name, "packetBounces")) c->packetBounces = v < 0 ? -1 : v;
     else if (name_is(name, "refillNodeMin")) c->refillNodeMin = v;
     else if (name_is(name, "refillTriMin")) c->refillTriMin = v;
     else if (name_is(name, "refillNodeLow")) c->refillNodeLow = v;

@@ -16,6 +16,8 @@
 #pragma once
 
 namespace rt {
+__device__ __forceinline__ void shadow_sun_packet(const SceneView& S, const FrameParams& F, const PathBuffers& P, const uint32_t* __restrict__ count,
+                                                  int bounce, uint2* lds, uint32_t bid, uint32_t nblk);      // rt_trace_packet.hip.h
 
 // shader.comp:104-125 on a pre-transformed triangle: true + t on a hit.
 __device__ __forceinline__ bool tri_t(float4 A, float4 B, float4 C, v3 o, v3 d, float* tOut) {
@@ -609,7 +611,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_refill(SceneView S, FramePa
 // straight on with the other instead of idling through the first kernel's drain.
 // Workgroup b of the launch runs the closest-hit body as workgroup b of a grid of gE, then the shadow body as workgroup
 // (gridDim - 1 - b) of a grid of gS: short queues therefore land on opposite ends of the launch and run side by side.
-// EXT: 0 extend_batch, 1 extend_refill.  SHD: 0 shadow_batch, 1 shadow_sun_batch, 2 shadow_refill<., false>, 3 shadow_refill<., true>.
+// EXT: 0 extend_batch, 1 extend_refill.  SHD: 0 shadow_batch, 1 shadow_sun_batch, 2 shadow_refill<., false>, 3 shadow_refill<., true>,
+// 4 shadow_sun_packet (coherent rays: bounce 0).
 // WIDE: the refill bodies walk the two-level nodes.
 template <int EXT, int SHD, bool WIDE = false>
 __global__ __launch_bounds__(RT_BLOCK, ((EXT == 1 && SHD != 2) ? (WIDE ? 5 : 6) : 1)) void k_trace_pair(SceneView S, FrameParams F, PathBuffers P,
@@ -627,8 +630,11 @@ __global__ __launch_bounds__(RT_BLOCK, ((EXT == 1 && SHD != 2) ? (WIDE ? 5 : 6) 
         if (SHD == 0) shadow_batch<false, false>(S, F, P, countShd, bounceShd, stats, lds, bs, gS);
         else if (SHD == 1) shadow_sun_batch(S, F, P, countShd, bounceShd, lds, bs, gS);
         else if (SHD == 2) shadow_refill<false, false, WIDE>(S, F, P, countShd, bounceShd, refillIdle, schedBits, stats, lds, bs, gS);
-        else shadow_refill<false, true, WIDE>(S, F, P, countShd, bounceShd, refillIdle, schedBits, stats, lds, bs, gS);
+        else if (SHD == 3) shadow_refill<false, true, WIDE>(S, F, P, countShd, bounceShd, refillIdle, schedBits, stats, lds, bs, gS);
+        else shadow_sun_packet(S, F, P, countShd, bounceShd, lds, bs, gS);
     }
 }
 
 }  // namespace rt
+
+#include "rt_trace_packet.hip.h"

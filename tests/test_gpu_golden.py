@@ -31,6 +31,11 @@ VARIANTS = {"culled": {"traversalMode": 0}, "reference_order": {"traversalMode":
             # the contribution log in two parts: an entry per slot for the first bounces, per queue position for the later ones
             "late_log_after_2": {"logDenseBounces": 2, "lateLogPercent": 100}, "late_log_after_1_pairs": {"logDenseBounces": 1, "lateLogPercent": 100, "kernelChoice": 3},
             "late_log_after_3_batch": {"logDenseBounces": 3, "lateLogPercent": 100, "refill": 0, "fusePairs": 0, "samplesPerPass": 2, "passStreams": 2},
+            # the sun's shadow rays traced a packet of 64 per wave (scalar loads, lane masks): every bounce, in joint and separate
+            # launches, beside batch and refill kernels; and never (scenes 2 and 3 have a point light: the knob does not apply)
+            "packet_all_bounces": {"packetBounces": 64}, "packet_separate": {"packetBounces": 64, "fusePairs": 0},
+            "packet_beside_refill": {"packetBounces": 2, "kernelChoice": 3, "wideNodes": 1}, "packet_beside_batch": {"packetBounces": 1, "kernelChoice": 0},
+            "packet_never": {"packetBounces": 0},
             # ... and a compact part too small for the frame: the core notices, renders the frame again with a dense log
             "late_log_overflow": {"logDenseBounces": 1, "lateLogPercent": 1}}
 
