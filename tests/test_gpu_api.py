@@ -119,6 +119,34 @@ def test_camera_moves_between_frames(oracle_lib, scene7):
     cs.Delete()
 
 
+def test_a_context_that_grows_and_shrinks(oracle_lib, scene4):
+    """One context, no new upload: a small frame, a frame 12 times the pixels with ten times the samples and twice the
+    bounces (the path buffers — one arena per array, sized for both pass shapes — are allocated again), the same with the
+    other pass shape pinned, and the small frame once more.  Every frame is the oracle's; the last equals the first."""
+    from raytracing_amd import ComputeShader
+    from tests.util import set_camera
+    from oracle import ref
+    cs = ComputeShader()
+    setup_core(cs, scene4, 48, 40, 4, 4)
+    shots = {}
+    for step, (W, H, spp, b, choice) in enumerate(((48, 40, 4, 4, -1), (200, 120, 40, 8, -1), (200, 120, 40, 8, 5), (48, 40, 4, 4, -1))):
+        cs.resize(W, H)
+        set_camera(cs, ref.DEFAULT_CAMERA, W, H)
+        cs.setInt("samplesPerPixel", spp)
+        cs.setInt("maxBounces", b)
+        cs.setInt("kernelChoice", choice)
+        imgs = _render(cs)
+        if (W, H) not in shots:
+            want = oracle_lib.render(scene4, oracle_lib.make_params(scene4, W, H, spp, b, math_mode=1))
+            for k, name in enumerate(("color", "albedo", "normal", "depth")):
+                assert same_floats(imgs[k], want[name]).all(), (step, name)
+            shots[(W, H)] = imgs
+        else:
+            assert all(same_floats(imgs[k], shots[(W, H)][k]).all() for k in range(4)), step
+        assert cs.stats()["rays_primary"] == W * H * spp
+    cs.Delete()
+
+
 def test_region_is_bit_identical_and_sample_ranges_sum(oracle_lib, scene4):
     from raytracing_amd import ComputeShader
     W, H, spp, b = 64, 48, 4, 6
