@@ -438,7 +438,7 @@ rt_status ensure_paths(rt_ctx* c, int nSets, uint32_t nslots, uint32_t slotsPerS
                        int alsoSets = 0, uint32_t alsoSlots = 0) {
     rt_status s;
     const SetBytes sb = set_bytes(c, nslots, lightSlots, maxBounces);
-    SetBytes also;
+    SetBytes also{};
     if (alsoSets > 0) also = set_bytes(c, alsoSlots, lightSlots, maxBounces);
     for (int a = 0; a < rt_ctx::A_COUNT; a++) {
         size_t need = sb.b[a] * (size_t)nSets;
