@@ -75,7 +75,7 @@ def test_sample_groups_and_pass_shapes_do_not_change_the_image(oracle_lib, scene
         assert same_floats(first[k], want[name]).all(), name
     tri0, hit0 = cs.primary_hits()
     rays0 = [cs.stats()[k] for k in ("rays_primary", "rays_bounce", "rays_shadow", "rays_shadow_skipped")]
-    defaults = {"sampleGroup": -1, "samplesPerPass": 64, "passStreams": 0, "autoPass": 1, "pathMemPercent": 50, "kernelChoice": -1,
+    defaults = {"sampleGroup": -1, "samplesPerPass": 64, "passStreams": 0, "autoPass": 1, "pathMemPercent": 75, "kernelChoice": -1,
                 "logDenseBounces": 0, "lateLogPercent": 25}
     for knobs in ({"sampleGroup": 0}, {"sampleGroup": 6}, {"sampleGroup": 3, "samplesPerPass": 12}, {"sampleGroup": 2, "samplesPerPass": 4, "passStreams": 3},
                   {"sampleGroup": 6, "samplesPerPass": 5, "autoPass": 0}, {"sampleGroup": 1, "samplesPerPass": 3, "passStreams": 2, "kernelChoice": 3},
