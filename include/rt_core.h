@@ -90,8 +90,11 @@ rt_status rt_upload_buffer(rt_ctx* ctx, uint32_t slot, const void* data, uint64_
  * shape (1: half the streams, twice the samples per pass), whatever
  * was measured, reported back in rt_stats.kernel_choice; a multi-GPU job gives every rank rank 0's), fusePairs (1 / 0: the
  * shadow rays of a bounce and the closest-hit rays of the next are traced by one launch), wideNodes (-1 / 0 / 1: the refill
- * kernels walk two-level nodes derived from the same tree, by default for BVHs far larger than the L2s; same images), refillIdle, refillNodeMin,
- * refillBlocksPerCU. */
+ * kernels walk two-level nodes derived from the same tree, by default for BVHs far larger than the L2s; same images),
+ * packetBounces (-1 / n: the sun's shadow rays of the first n bounces are traced 64 to a wave through scalar loads; -1 = bounce
+ * 0 where the compact BVH is at most 1 MB), refillFromBounce, autoPass, sunKernel, tuneCache, refillIdle, refillNodeMin,
+ * refillTriMin, refillNodeLow, refillDefer, refillBlocksPerCU (all in INTEGRATION.md section 7, with defaults). None of them
+ * changes an image. */
 rt_status rt_set_int(rt_ctx* ctx, const char* name, int32_t v);
 rt_status rt_set_float(rt_ctx* ctx, const char* name, float v);
 rt_status rt_set_vec2(rt_ctx* ctx, const char* name, const float v[2]);
